@@ -1,0 +1,155 @@
+/*
+ * trajdiff_hip.h — C ABI of libtrajdiff_hip.so: the MI355X (gfx950) kernels behind the
+ * TrajectoryDiffusion denoising hot path (TrajUNet forward + DiffusionManager steps).
+ *
+ * The reference (JinmingWang/TrajectoryDiffusion) has no FFI: its hot path is Python calling
+ * PyTorch ATen ops.  Every entry point below therefore cites the reference *call site* whose
+ * ATen work it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void*; all entry points are asynchronous and
+ *     stream-ordered, allocate nothing, free nothing and never synchronise;
+ *   - return 0 on success, a TDX_ERR_* code otherwise (tdx_last_error() gives the text);
+ *     arguments are validated on the host BEFORE any launch;
+ *   - activations are channels-last rows: tensor (B, L, C) is B*L rows of C contiguous
+ *     elements of `dtype` (TDX_F32 or TDX_BF16); model inputs/outputs stay (B, 2, L) fp32
+ *     exactly as the reference's forward() takes/returns them.
+ */
+#ifndef TRAJDIFF_HIP_H
+#define TRAJDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TDX_OK = 0, TDX_ERR_ARG = 1, TDX_ERR_HIP = 2, TDX_ERR_UNSUPPORTED = 3 };
+enum { TDX_F32 = 0, TDX_BF16 = 1 };
+enum { TDX_ACT_NONE = 0, TDX_ACT_LEAKY = 1, TDX_ACT_SWISH = 2 };
+
+/* Library / error state ---------------------------------------------------------------- */
+const char* tdx_last_error(void);   /* thread-local text of the last failure */
+int tdx_version(void);
+/* Launch geometry used for the last tdx_conv_gemm call of this thread (for bench/roofline). */
+int tdx_device_ok(void);            /* 0 iff the current device is gfx950 */
+
+/* One K-segment of the implicit GEMM: a (source tensor, taps) pair.  Output row n = (b, l)
+ * consumes, for tap t, source row  b*lin + map(l*stride + t - (taps==3))  or zeros when that
+ * virtual index falls outside [0, lvirt) — i.e. Conv1d's zero padding.  `upmap` (device int32
+ * [lvirt], may be NULL = identity) is F.interpolate(mode='nearest')'s source index table. */
+typedef struct {
+  const void* src;      /* (B, lin, src_ld) activations */
+  const int32_t* upmap; /* NULL or [lvirt] nearest-upsample source rows */
+  int32_t src_ld;       /* elements per source row */
+  int32_t ch_off;       /* first source channel consumed */
+  int32_t cin;          /* channels consumed; multiple of 64 (bf16) / 32 (fp32) */
+  int32_t taps;         /* 1 or 3 */
+  int32_t stride;       /* 1 or 2 */
+  int32_t lin;          /* source trajectory length */
+  int32_t lvirt;        /* virtual (post-upsample, pre-stride) length */
+  int32_t reserved;
+} tdx_kseg;
+
+/* Conv1d (k=3 / k=1, stride 1/2, optional nearest-upsampled input, optional channel-concat of
+ * several sources, optional fused 1x1 shortcut as an extra segment) as ONE gathered GEMM on MFMA:
+ *   out[n, co] = act( sum_seg sum_t sum_ci  w[co, k(seg,t,ci)] * src_seg[row(n,t), ch_off+ci]
+ *                     + bias[co] + ebias[b(n), co] + tbias[co] ) + res[n, co]
+ * Replaces: nn.Conv1d call sites Models/TrajUNet.py:52,61 and Models/TrajUNetBlocks.py:77,86,89,
+ * 110,112, the embed_proj add (:98-99), the shortcut add (:99), torch.cat (TrajUNet.py:90) and
+ * F.interpolate (TrajUNet.py:93); nn.Linear call sites TrajUNetBlocks.py:20-40 with lout = 1. */
+typedef struct {
+  tdx_kseg seg[4];
+  int32_t nseg;
+  int32_t dtype;        /* TDX_F32 / TDX_BF16: element type of src, w, res, out */
+  const void* w;        /* packed weights [cout][ktot], ktot = sum_seg taps*cin, K order = seg, tap, ci */
+  const float* bias;    /* [cout] or NULL */
+  const float* ebias;   /* per-sample bias rows (B, ebias_ld), or NULL */
+  const float* tbias;   /* per-call bias vector (indexed like one ebias row), or NULL */
+  int32_t ebias_ld;
+  int32_t ebias_off;    /* column of ebias/tbias that maps to co = 0 */
+  const void* res;      /* residual (B*lout, res_ld) added after act, or NULL */
+  int32_t res_ld;
+  int32_t act;          /* TDX_ACT_* applied before the residual add */
+  void* out;            /* (B*lout, out_ld) */
+  int32_t out_ld;
+  int32_t out_off;      /* first output channel written (concat writes) */
+  int32_t B, lout, cout;/* cout multiple of 128 */
+  int32_t reserved;
+} tdx_conv_desc;
+int tdx_conv_gemm(const tdx_conv_desc* host_desc, void* stream);
+
+/* GroupNorm(groups, C, eps, affine) [+ Swish] over channels-last rows, one pass to memory:
+ *   out[b, l, out_off + c] = act((x[b,l,c] - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c])
+ * Replaces nn.GroupNorm + Swish at Models/TrajUNetBlocks.py:75-76, :83-84, :109,
+ * Models/TrajUNet.py:43 and Models/ModelUtils.py:14.  C/groups must be a power of two >= 4. */
+int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
+                      const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
+                      int32_t groups, float eps, int32_t act, int32_t dtype, void* stream);
+
+/* Stem Conv1d(2 -> C0, k3, p1): x (B, 2, L) fp32 channels-first -> out (B, L, C0) rows.
+ * w is the reference layout (C0, 2, 3) fp32.  Replaces Models/TrajUNet.py:21,107. */
+int tdx_stem_conv(const float* x, const float* w, const float* bias, void* out, int32_t B, int32_t L,
+                  int32_t C0, int32_t dtype, void* stream);
+
+/* Head Conv1d(C0 -> 2, k3, p1) on already group-normalised rows a (B, L, C0) -> eps (B, 2, L)
+ * fp32 channels-first.  w is (2, C0, 3) fp32.  Replaces Models/TrajUNet.py:44,112. */
+int tdx_head_conv(const void* a, const float* w, const float* bias, float* out, int32_t B, int32_t L,
+                  int32_t C0, int32_t dtype, void* stream);
+
+/* Mid-block single-head attention core on qkv rows (B, L, 3C) [q | k | v]:
+ *   o[b] = softmax(q k^T / sqrt(C)) v   -> (B, L, C).   L <= 64.
+ * Replaces transpose/split/bmm/softmax/bmm at Models/TrajUNetBlocks.py:121-123. */
+int tdx_attention(const void* qkv, void* out, int32_t B, int32_t L, int32_t C, int32_t dtype, void* stream);
+
+/* WideAndDeepEmbedBlock input gather (Models/TrajUNetBlocks.py:53-58): builds, all fp32,
+ *   pe      (B, 128)   = pos_enc[time]
+ *   catvec  (B, 1280)  = [cell_emb[cat0..3] | day_emb[cat4]]
+ *   deep_in (B, 1024)  columns 768..1023 = leaky0.1(wide_fc(num))   (columns 0..767 are written by
+ *                        the categorical_fc GEMM).  Indices are validated on the device: an
+ *                        out-of-range index sets *err_flag (device int32) instead of faulting. */
+int tdx_embed_gather(const int64_t* time, const int64_t* cat, const float* num, const float* pos_enc,
+                     int32_t max_time, const float* cell_emb, const float* day_emb, const float* wide_w,
+                     const float* wide_b, float* pe, float* catvec, float* deep_in, int32_t B,
+                     int32_t* err_flag, void* stream);
+
+/* DDPM posterior step, DiffusionManager.py:46-55, fused into one coalesced pass:
+ *   x = (x - c_eps * eps) / sqrt_alpha + sigma * z     coef = {beta/sqrt(1-abar), sqrt(alpha), sqrt(beta)} (device, 3 floats)
+ * z = injected noise tensor, or NULL to draw N(0,1) in-kernel (Philox4x32-10 + Box-Muller keyed by
+ * (seed ^ dyn_seed, step, first_elem + element index) so results do not depend on how the batch is sharded;
+ * step_ctr is NULL or a device int32[4] = {step, dyn_seed_lo, dyn_seed_hi, reserved}, read at run time so
+ * a captured graph can be replayed with a new step / seed).  sigma == 0 (t == 0) adds no noise.  In place on x. */
+int tdx_ddpm_update(float* x, const float* eps, const float* z, const float* coef, int64_t n,
+                    uint64_t seed, const int32_t* step_ctr, int64_t first_elem, void* stream);
+
+/* DDIM (eta = 0) step on the same alpha-bar table (not in the reference):
+ *   x0 = (x - s1m_t*eps)/sa_t ; x = sa_p*x0 + s1m_p*eps     coef = {s1m_t, 1/sa_t, sa_p, s1m_p}. */
+int tdx_ddim_update(float* x, const float* eps, const float* coef, int64_t n, void* stream);
+
+/* Sampling-loop bookkeeping kept on the device so one captured hipGraph can be replayed T times:
+ * reads step = *step_ctr, copies coef_table[step, 0:ncoef] -> coef_cur and
+ * tbias_table[step, 0:ntb] -> tbias_cur, fills t_vec[0:B] = step_to_t[step], then *step_ctr = step + 1.
+ * Replaces the host-side indexing in DiffusionManager.py:46-48,70-72. */
+int tdx_step_prepare(int32_t* step_ctr, const float* coef_table, int32_t ncoef, float* coef_cur,
+                     const float* tbias_table, int32_t ntb, float* tbias_cur, const int32_t* step_to_t,
+                     int64_t* t_vec, int32_t B, int32_t nsteps, void* stream);
+
+/* q-sample, DiffusionManager.py:33: x_t = sqrt_ab[t[b]] * x0 + sqrt_1m_ab[t[b]] * eps. */
+int tdx_q_sample(const float* x0, const float* eps, const int64_t* t, const float* sqrt_ab,
+                 const float* sqrt_1m_ab, int32_t T, float* out, int32_t B, int32_t per_sample,
+                 int32_t* err_flag, void* stream);
+
+/* DidiTrajectoryDataset.__getitem__ batched (Dataset/DidiDataset.py:138-174):
+ *   lon_lat_raw (B, L, 2) fp32 degrees, minutes (B, L) fp32, stats = {mean_t, mean_lon, mean_lat,
+ *   std_t, std_lon, std_lat}, bounds = 257 fp32 Gaussian-quantile cell boundaries.
+ * Outputs lon_lat (B, 2, L) fp32 z-scored, cat (B, 5) int64, num (B, 3) fp32, times (B, L) fp32. */
+int tdx_didi_items(const float* lon_lat_raw, const float* minutes, const float* stats, const float* bounds,
+                   float* lon_lat, int64_t* cat, float* num, float* times, int32_t B, int32_t L, void* stream);
+/* Inverse z-score (not in the reference): lon_lat (B, 2, L) -> degrees (B, L, 2). */
+int tdx_didi_denorm(const float* lon_lat, const float* stats, float* out_deg, int32_t B, int32_t L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJDIFF_HIP_H */

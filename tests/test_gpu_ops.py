@@ -1,0 +1,272 @@
+"""GPU: every C-ABI kernel against a plain fp32 PyTorch-CPU statement of the same op (op-level parity)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import DiffusionOracle, nearest_index_map  # noqa: E402
+from oracle.trajunet_oracle import swish  # noqa: E402
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}  # max |err| relative to max |ref|
+
+
+def _eng():
+    from trajectorydiffusion_amd import engine, _lib
+    return engine, _lib
+
+
+def rows(x, dt):  # (B, C, L) cpu -> (B, L, C) cuda
+    return x.permute(0, 2, 1).contiguous().to("cuda", dt)
+
+
+def unrows(r):
+    return r.float().cpu().permute(0, 2, 1).contiguous()
+
+
+def q(x, dt):  # what the kernel actually sees after the dtype cast
+    return x.to(dt).float()
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def run_conv(dt, x, w, b, stride=1, upmap_to=None, act=0, res=None, ebias=None, tbias=None):
+    engine, _lib = _eng()
+    B, Ci, L = x.shape
+    Co = w.shape[0]
+    pg = engine.Program(torch.device("cuda"), dt)
+    src = rows(x, dt)
+    if upmap_to is not None:
+        lo = upmap_to
+        seg = engine.Seg(src, Ci, Ci, L, taps=w.shape[2], upmap=engine.nearest_map(L, lo).cuda(), lvirt=lo)
+    else:
+        lo = (L - 1) // stride + 1 if w.shape[2] == 3 else L
+        seg = engine.Seg(src, Ci, Ci, L, taps=w.shape[2], stride=stride)
+    out = torch.full((B, lo, Co), float("nan"), device="cuda", dtype=dt)
+    kw = {}
+    if res is not None:
+        kw.update(res=rows(res, dt), res_ld=Co)
+    if ebias is not None or tbias is not None:
+        kw.update(ebias=None if ebias is None else ebias.cuda(), tbias=None if tbias is None else tbias.cuda(),
+                  ebias_ld=Co + 8, ebias_off=8)
+    pg.conv([seg], engine.pack_conv_weight(w.cuda(), dt), None if b is None else b.cuda(), out, Co, B, lo, Co, act=act, **kw)
+    pg.run()
+    torch.cuda.synchronize()
+    return unrows(out)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,L,Ci,Co", [(3, 13, 64, 128), (2, 200, 128, 128), (5, 25, 256, 256), (1, 7, 96, 96), (130, 1, 128, 256),
+                                       (2, 50, 32, 64)])
+def test_conv3_stride1(dt, B, L, Ci, Co):
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, 3, generator=g) / (3 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv1d(q(x, dt), q(w, dt), b, padding=1)
+    assert rel(run_conv(dt, x, w, b), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("L", [25, 200, 13, 14, 2])
+def test_conv3_stride2(dt, L):
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(3, 128, L, generator=g)
+    w = torch.randn(128, 128, 3, generator=g) / 20
+    b = torch.randn(128, generator=g)
+    ref = F.conv1d(q(x, dt), q(w, dt), b, stride=2, padding=1)
+    assert rel(run_conv(dt, x, w, b, stride=2), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("li,lo", [(13, 25), (25, 50), (100, 200), (12, 24), (24, 47)])
+def test_conv3_on_nearest_upsample(dt, li, lo):
+    g = torch.Generator().manual_seed(li)
+    x = torch.randn(2, 128, li, generator=g)
+    w = torch.randn(128, 128, 3, generator=g) / 20
+    b = torch.randn(128, generator=g)
+    up = F.interpolate(q(x, dt), size=lo, mode="nearest")
+    assert torch.equal(up, q(x, dt)[:, :, nearest_index_map(li, lo)])
+    ref = F.conv1d(up, q(w, dt), b, padding=1)
+    assert rel(run_conv(dt, x, w, b, upmap_to=lo), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv1_epilogue_bias_act_residual(dt):
+    g = torch.Generator().manual_seed(7)
+    B, L, Ci, Co = 4, 13, 128, 384
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, 1, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g)
+    res = torch.randn(B, Co, L, generator=g)
+    eb = torch.randn(B, Co + 8, generator=g)
+    tb = torch.randn(Co + 8, generator=g)
+    pre = F.conv1d(q(x, dt), q(w, dt), b) + eb[:, 8:, None] + tb[None, 8:, None]
+    for act, fn in ((0, lambda v: v), (1, lambda v: F.leaky_relu(v, 0.1)), (2, swish)):
+        ref = fn(pre) + q(res, dt)
+        assert rel(run_conv(dt, x, w, b, act=act, res=res, ebias=eb, tbias=tb), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv_concat_plus_shortcut_segments(dt):
+    """conv3 over an activated tensor + 1x1 shortcut over two raw concat sources, one launch (decoder ResnetBlock conv2)."""
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(11)
+    B, L, C, Co = 3, 25, 64, 128
+    a2 = torch.randn(B, Co, L, generator=g)
+    xa, xb = torch.randn(B, C, L, generator=g), torch.randn(B, C, L, generator=g)
+    w2 = torch.randn(Co, Co, 3, generator=g) / 20
+    wsc = torch.randn(Co, 2 * C, 1, generator=g) / 12
+    b = torch.randn(Co, generator=g)
+    ref = F.conv1d(q(a2, dt), q(w2, dt), b, padding=1) + F.conv1d(torch.cat([q(xa, dt), q(xb, dt)], 1), q(wsc, dt))
+    pg = engine.Program(torch.device("cuda"), dt)
+    wp = torch.cat([engine.pack_conv_weight(w2.cuda(), dt), engine.pack_conv_weight(wsc.cuda(), dt)], dim=1).contiguous()
+    out = torch.empty((B, L, Co), device="cuda", dtype=dt)
+    segs = [engine.Seg(rows(a2, dt), Co, Co, L), engine.Seg(rows(xa, dt), C, C, L, taps=1), engine.Seg(rows(xb, dt), C, C, L, taps=1)]
+    pg.conv(segs, wp, b.cuda(), out, Co, B, L, Co)
+    pg.run()
+    assert rel(unrows(out), ref) < TOL[dt]
+
+
+def test_conv_rejects_bad_arguments():
+    engine, _lib = _eng()
+    pg = engine.Program(torch.device("cuda"), torch.float32)
+    x = torch.zeros((2, 10, 32), device="cuda")
+    out = torch.zeros((2, 10, 128), device="cuda")
+    w = torch.zeros((128, 96), device="cuda")
+    pg.conv([engine.Seg(x, 32, 32, 10, taps=3, stride=3)], w, None, out, 128, 2, 10, 128)
+    with pytest.raises(_lib.TdxError, match="stride"):
+        pg.run()
+    pg = engine.Program(torch.device("cuda"), torch.float32)
+    pg.conv([engine.Seg(x, 32, 32, 10, taps=3)], w, None, out, 128, 2, 11, 128)  # wrong lout
+    with pytest.raises(_lib.TdxError, match="output rows"):
+        pg.run()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,L,C,act", [(3, 200, 128, 2), (2, 13, 1024, 2), (2, 13, 2048, 2), (4, 25, 256, 0), (1, 100, 512, 2), (2, 7, 4096, 0)])
+def test_groupnorm_act(dt, B, L, C, act):
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(C + L)
+    x = torch.randn(B, C, L, generator=g) * 2 + 0.7
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(q(x, dt), 32, gamma, beta, eps=1e-6)
+    ref = swish(ref) if act == 2 else ref
+    pg = engine.Program(torch.device("cuda"), dt)
+    out = torch.zeros((B, L, C + 64), device="cuda", dtype=dt)
+    pg.groupnorm(rows(x, dt), C, out, C + 64, 64, gamma.cuda(), beta.cuda(), 0, B, L, C, 32, 1e-6, act)
+    pg.run()
+    got = unrows(out)
+    assert rel(got[:, 64:], ref) < (3e-5 if dt == torch.float32 else 1.2e-2)
+    assert float(got[:, :64].abs().max()) == 0.0  # columns outside [out_off, out_off + C) untouched
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,L,C", [(3, 13, 1024), (2, 16, 256), (1, 64, 128), (2, 1, 128)])
+def test_attention(dt, B, L, C):
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(B, L, 3 * C, generator=g)
+    qq = q(qkv, dt)
+    qv, kv, vv = torch.split(qq, C, dim=2)
+    ref = torch.bmm(torch.softmax(torch.bmm(qv, kv.transpose(1, 2)) / C ** 0.5, dim=2), vv)
+    out = torch.empty((B, L, C), device="cuda", dtype=dt)
+    _lib.check(_lib.lib().tdx_attention(qkv.to("cuda", dt).data_ptr(), out.data_ptr(), B, L, C, _lib.dtype_code(dt), _lib.stream_ptr()))
+    assert rel(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("L", [200, 187, 1])
+def test_stem_and_head(dt, L):
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(L)
+    B, C0 = 3, 128
+    x = torch.randn(B, 2, L, generator=g)
+    w, b = torch.randn(C0, 2, 3, generator=g), torch.randn(C0, generator=g)
+    out = torch.empty((B, L, C0), device="cuda", dtype=dt)
+    code = _lib.dtype_code(dt)
+    _lib.check(_lib.lib().tdx_stem_conv(x.cuda().data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(), out.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
+    ref = F.conv1d(x, w, b, padding=1)
+    assert rel(unrows(out), ref) < (1e-6 if dt == torch.float32 else 5e-3)
+    a = torch.randn(B, C0, L, generator=g)
+    wh, bh = torch.randn(2, C0, 3, generator=g) / 20, torch.randn(2, generator=g)
+    eps = torch.empty((B, 2, L), device="cuda")
+    _lib.check(_lib.lib().tdx_head_conv(rows(a, dt).data_ptr(), wh.cuda().data_ptr(), bh.cuda().data_ptr(), eps.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
+    assert rel(eps.cpu(), F.conv1d(q(a, dt), wh, bh, padding=1)) < 2e-5
+
+
+def test_ddpm_update_injected_noise_matches_reference_formula():
+    from trajectorydiffusion_amd import DiffusionManager
+    dm = DiffusionManager(1e-4, 0.05, 500, device="cuda")
+    o = DiffusionOracle(1e-4, 0.05, 500)
+    g = torch.Generator().manual_seed(0)
+    for shape in [(16, 2, 200), (3, 2, 187), (1, 2, 1)]:
+        x, e, z = (torch.randn(shape, generator=g) for _ in range(3))
+        for t in (499, 250, 1, 0):
+            got = dm.diffusionBackwardStep(x.cuda(), t, e.cuda(), noise=z.cuda()).cpu()
+            ref = o.posterior_step(x, t, e, z)
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-6 * float(ref.abs().max()))
+    with pytest.raises(IndexError):
+        dm.diffusionBackwardStep(x.cuda(), 500, e.cuda())
+
+
+def test_ddpm_update_philox_noise_is_standard_normal_and_shard_invariant():
+    from trajectorydiffusion_amd import _lib
+    lib = _lib.lib()
+    n = 1 << 22
+    coef = torch.tensor([0.0, 1.0, 1.0], device="cuda")  # x = 0 + 1 * z
+    ctr = torch.tensor([5, 123, 456, 0], dtype=torch.int32, device="cuda")
+    zeros = torch.zeros(n, device="cuda")
+
+    def draw(first, count, seed=99):
+        x = torch.zeros(count, device="cuda")
+        _lib.check(lib.tdx_ddpm_update(x.data_ptr(), zeros.data_ptr(), None, coef.data_ptr(), count, seed, ctr.data_ptr(), first, _lib.stream_ptr()))
+        return x
+    z = draw(0, n)
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.var()) - 1) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3) < 0.05 and float(z.abs().max()) < 7
+    half = n // 2
+    assert torch.equal(torch.cat([draw(0, half), draw(half, half)]), z)  # batch shards draw what the whole batch draws
+    assert not torch.equal(draw(0, 1024, seed=100), z[:1024])
+    ctr[0] = 6
+    assert not torch.equal(draw(0, 1024), z[:1024])
+
+
+def test_q_sample():
+    from trajectorydiffusion_amd import DiffusionManager
+    dm = DiffusionManager(1e-4, 0.05, 500, device="cuda")
+    o = DiffusionOracle(1e-4, 0.05, 500)
+    g = torch.Generator().manual_seed(1)
+    x0, e = torch.randn(8, 2, 200, generator=g), torch.randn(8, 2, 200, generator=g)
+    t = torch.tensor([0, 1, 17, 250, 499, 3, 3, 498])
+    got = dm.diffusionForward(x0.cuda(), t.cuda(), e.cuda()).cpu()
+    np.testing.assert_array_equal(got.numpy(), o.q_sample(x0, t, e).numpy())  # mul, mul, add in fp32: bit-exact
+    with pytest.raises(IndexError):
+        dm.diffusionForward(x0.cuda(), torch.full((8,), 500).cuda(), e.cuda())
+
+
+def test_didi_items_match_golden(golden_dir, tmp_path):
+    import os
+    from _synth import synth_raw_trajectories
+    from trajectorydiffusion_amd import DidiTrajectoryDataset, collectFunc
+    g = np.load(os.path.join(golden_dir, "dataset.npz"))
+    root = tmp_path / "nov"
+    root.mkdir()
+    torch.save(synth_raw_trajectories(6, 200, seed=4), str(root / "gps_20161101.pt"))
+    ds = DidiTrajectoryDataset(str(root), 200, [21599.4980, 108.950773428688, 34.24354179925547],
+                               [12470.9102, 0.02129110045580343, 0.019358855648211895])
+    assert ds.loadNextFiles(1) and len(ds) == g["lon_lat"].shape[0]
+    ll, cat, num, tm = collectFunc([ds[i] for i in range(len(ds))])
+    np.testing.assert_array_equal(ll.cpu().numpy(), g["lon_lat"])   # z-score is (x - mean) / std in fp32: bit-exact
+    np.testing.assert_array_equal(tm.cpu().numpy(), g["times"])
+    np.testing.assert_array_equal(cat.cpu().numpy(), g["cat"])
+    np.testing.assert_allclose(num.cpu().numpy(), g["num"], rtol=2e-6)  # 199-term fp32 sum, different association
+    deg = ds.denormalize(ll)
+    raw = torch.stack([a for a, _ in ds.dataset_part])
+    assert float((deg.cpu() - raw).abs().max()) < 2e-5  # degrees; fp32 ulp at 108.95 deg is 7.6e-6 (~0.8 m)
+    with pytest.raises(ValueError):
+        DidiTrajectoryDataset(str(tmp_path), 200, [0, 0, 0], [1, 1, 1])

@@ -1,0 +1,248 @@
+"""TrajUNet with the reference's constructor / forward signature / state_dict keys
+(reference Models/TrajUNet.py:4-112), executed as a static program of HIP kernel launches.
+
+forward(x (B,2,L) fp32, time (B,) int64, cat_attr (B,5) int64, num_attr (B,3) fp32) -> (B,2,L) fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, engine
+from .._lib import ACT_NONE, TdxError
+from .TrajUNetBlocks import AttnBlock, ResnetBlock, WideAndDeepEmbedBlock, _HipBlock
+
+
+class UNetProgram:
+    """One compiled (B, L, dtype) instance of the forward pass plus its static I/O buffers."""
+
+    def __init__(self, model: "TrajUNet", B: int, L: int, dtype: torch.dtype, device: torch.device, split_embed: bool):
+        self.B, self.L, self.dtype, self.split_embed = B, L, dtype, split_embed
+        pg = engine.Program(device, dtype)
+        self.pg = pg
+        f32 = torch.float32
+        self.x = pg.alloc((B, 2, L), f32)          # x_t in, updated in place by the sampler
+        self.eps = pg.alloc((B, 2, L), f32)        # eps_hat out
+        self.time = pg.alloc((B,), torch.int64)
+        self.cat = pg.alloc((B, 5), torch.int64)
+        self.num = pg.alloc((B, 3), f32)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        self.emb = pg.alloc((B, 256), f32)         # swish([time_embed | attr_embed])  (B, 256)
+        packed = model.packed_weights(dtype)
+        NE = model.embed_cols
+        self.ebias = pg.alloc((B, NE), f32)
+        self.tbias: Optional[torch.Tensor] = None
+        self.embed_pg: Optional[engine.Program] = None
+        if split_embed:
+            # sampling: every sample shares t, and attributes do not change between steps, so
+            #   W_e . swish([time | attr]) = W_e[:, :128] . swish(time)  +  W_e[:, 128:] . swish(attr)
+            # the attr half (+ bias) is computed once per call into ebias, the time half once per step table row.
+            self.tbias = pg.alloc((NE,), f32)
+            ep = engine.Program(device, f32)
+            engine.emit_embed(ep, model.embed_block, packed, B, self.time, self.cat, self.num, self.err, self.emb, want_time=False)
+            ep.conv([engine.Seg(self.emb, 256, 128, 1, taps=1, ch_off=128)], packed["embed_proj.w_attr"], packed["embed_proj.b"],
+                    self.ebias, NE, B, 1, NE, dtype_code=_lib.TDX_F32, name="embed_proj.attr")
+            self.embed_pg = ep
+        else:
+            engine.emit_embed(pg, model.embed_block, packed, B, self.time, self.cat, self.num, self.err, self.emb)
+            pg.conv([engine.Seg(self.emb, 256, 256, 1, taps=1)], packed["embed_proj.w"], packed["embed_proj.b"], self.ebias, NE, B, 1,
+                    NE, dtype_code=_lib.TDX_F32, name="embed_proj")
+        self._emit_unet(model, packed)
+
+    def _emit_unet(self, m: "TrajUNet", packed: Dict[str, torch.Tensor]) -> None:
+        pg, B, L = self.pg, self.B, self.L
+        cs, NE = m.channel_schedule, m.embed_cols
+        eb, tb = self.ebias, self.tbias
+        lens = [L]
+        for _ in range(m.stages):
+            lens.append(engine.conv_out_len(lens[-1], 2))
+        # stem (reference TrajUNet.py:107); only its LENGTH is used as a skip (:109 + :93)
+        cur = pg.alloc((B, L, cs[0]))
+        pg.call("stem", pg.lib.tdx_stem_conv, self.x.data_ptr(), engine.fp32_param(m.stem.weight, "stem.weight").data_ptr(),
+                engine.fp32_param(m.stem.bias, "stem.bias").data_ptr(), cur.data_ptr(), B, L, cs[0], pg.code, keep=[cur])
+        downs: List[torch.Tensor] = []
+        cur_is_skip = False  # skip tensors stay live until the decoder has consumed them
+        for i in range(m.stages):  # encoder, :65-78
+            li, co = lens[i], cs[i + 1]
+            for j in range(m.res_blocks):
+                key = f"down_blocks.{i}.{j}."
+                blk = m.down_blocks[i][j]
+                nxt = engine.emit_resblock(pg, blk, packed, key, [(cur, blk.in_c)], B, li, eb, tb, NE, m.embed_offsets[key])
+                if not cur_is_skip:
+                    pg.release(cur)
+                cur, cur_is_skip = nxt, False
+            dconv = m.down_blocks[i][m.res_blocks]
+            d = pg.alloc((B, lens[i + 1], co))
+            pg.conv([engine.Seg(cur, co, co, li, stride=2)], packed[f"down_blocks.{i}.down.w"],
+                    engine.fp32_param(dconv.bias, f"down_blocks.{i}.{m.res_blocks}.bias"), d, co, B, lens[i + 1], co,
+                    name=f"down_blocks.{i}.down")
+            pg.release(cur)
+            downs.append(d)
+            cur, cur_is_skip = d, True
+        lm = lens[-1]
+        key = "mid_attn_block."
+        cur = m.mid_attn_block.emit(pg, packed, key, downs[-1], B, lm, eb, tb, NE,
+                                    (m.embed_offsets[key + "res1."], m.embed_offsets[key + "res2."]))
+        for i in range(m.stages):  # decoder, :81-95
+            skip = downs[-i - 1]
+            li = lens[m.stages - i]
+            lo = lens[m.stages - i - 1]
+            cskip = cs[m.stages - i]
+            co = cs[m.stages - i - 1]
+            srcs: List[Tuple[torch.Tensor, int]] = [(cur, cskip), (skip, cskip)]
+            for j in range(m.res_blocks - 1):  # up_stage[:-2]: the last ResnetBlock of each stage is never executed
+                key = f"up_blocks.{i}.{j}."
+                blk = m.up_blocks[i][j]
+                nxt = engine.emit_resblock(pg, blk, packed, key, srcs, B, li, eb, tb, NE, m.embed_offsets[key])
+                for t, _ in srcs:
+                    pg.release(t)
+                srcs = [(nxt, co)]
+            cur = srcs[0][0]
+            upmap = engine.nearest_map(li, lo).to(pg.device)
+            uconv = m.up_blocks[i][m.res_blocks]
+            nxt = pg.alloc((B, lo, co))
+            pg.conv([engine.Seg(cur, co, co, li, upmap=upmap, lvirt=lo)], packed[f"up_blocks.{i}.up.w"],
+                    engine.fp32_param(uconv.bias, f"up_blocks.{i}.{m.res_blocks}.bias"), nxt, co, B, lo, co, name=f"up_blocks.{i}.up")
+            pg.release(cur)
+            cur = nxt
+        gn, hconv = m.head[0], m.head[1]
+        a = pg.alloc((B, L, cs[0]))
+        pg.groupnorm(cur, cs[0], a, cs[0], 0, engine.fp32_param(gn.weight, "head.0.weight"), engine.fp32_param(gn.bias, "head.0.bias"), 0,
+                     B, L, cs[0], gn.num_groups, gn.eps, ACT_NONE, name="head.gn")
+        pg.call("head.conv", pg.lib.tdx_head_conv, a.data_ptr(), engine.fp32_param(hconv.weight, "head.1.weight").data_ptr(),
+                engine.fp32_param(hconv.bias, "head.1.bias").data_ptr(), self.eps.data_ptr(), B, L, cs[0], pg.code, keep=[a])
+
+    def load_inputs(self, x, time, cat_attr, num_attr) -> None:
+        self.x.copy_(x)
+        self.time.copy_(time)
+        self.cat.copy_(cat_attr)
+        self.num.copy_(num_attr)
+
+    def run(self) -> None:
+        self.pg.run()
+
+
+class TrajUNet(_HipBlock):
+    def __init__(self, channel_schedule: List[int], traj_length: int = 200, diffusion_steps: int = 300, res_blocks: int = 2) -> None:
+        super().__init__()
+        if res_blocks < 2:
+            raise TdxError("TrajUNet: res_blocks must be >= 2 (with 1 the reference's decoder feeds a 2C-channel tensor to a C-channel conv)")
+        self.channel_schedule = list(channel_schedule)
+        self.stages = len(channel_schedule) - 1
+        self.res_blocks = res_blocks
+        self.diffusion_steps = diffusion_steps  # traj_length is unused, as in the reference (:10)
+        cs = self.channel_schedule
+        self.embed_block = WideAndDeepEmbedBlock(diffusion_steps, hidden_dim=256, embed_dim=128)
+        self.stem = nn.Conv1d(2, cs[0], 3, 1, 1)
+        self.down_blocks = nn.ModuleList()
+        for i in range(self.stages):
+            layers = [ResnetBlock(cs[i], cs[i + 1], norm_groups=32)]
+            layers += [ResnetBlock(cs[i + 1], norm_groups=32) for _ in range(res_blocks - 1)]
+            layers.append(nn.Conv1d(cs[i + 1], cs[i + 1], 3, 2, 1))  # downsample
+            self.down_blocks.append(nn.ModuleList(layers))
+        self.mid_attn_block = AttnBlock(cs[-1], norm_groups=32)
+        self.up_blocks = nn.ModuleList()
+        for i in range(self.stages):
+            cin, cout = cs[self.stages - i], cs[self.stages - i - 1]
+            layers = [ResnetBlock(cin * 2, cout, norm_groups=32)]
+            layers += [ResnetBlock(cout, norm_groups=32) for _ in range(res_blocks - 1)]  # last one: parameters only, never run
+            layers.append(nn.Conv1d(cout, cout, 3, 1, 1))  # conv after the nearest upsample
+            self.up_blocks.append(nn.ModuleList(layers))
+        self.head = nn.Sequential(nn.GroupNorm(32, cs[0]), nn.Conv1d(cs[0], 2, 3, 1, 1))
+
+        # column layout of the fused embed_proj GEMM: one (B, embed_cols) bias matrix for every executed ResnetBlock
+        self.embed_offsets: Dict[str, int] = {}
+        off = 0
+        for key, blk in self.executed_resblocks():
+            self.embed_offsets[key] = off
+            off += blk.out_c
+        self.embed_cols = off
+        self._packed: Dict[torch.dtype, Tuple[int, Dict[str, torch.Tensor]]] = {}
+        self._programs: Dict[Tuple, UNetProgram] = {}
+
+    # ---- structure helpers ---------------------------------------------------------------------
+    def executed_resblocks(self):
+        for i in range(self.stages):
+            for j in range(self.res_blocks):
+                yield f"down_blocks.{i}.{j}.", self.down_blocks[i][j]
+        yield "mid_attn_block.res1.", self.mid_attn_block.res1
+        yield "mid_attn_block.res2.", self.mid_attn_block.res2
+        for i in range(self.stages):
+            for j in range(self.res_blocks - 1):
+                yield f"up_blocks.{i}.{j}.", self.up_blocks[i][j]
+
+    def _version(self) -> int:
+        return sum(p._version for p in self.parameters())
+
+    def packed_weights(self, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+        """GEMM-layout weights in the compute dtype, rebuilt whenever a parameter changes."""
+        ver = self._version()
+        hit = self._packed.get(dtype)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        out: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            for key, blk in self.executed_resblocks():
+                engine.pack_resblock(blk, key, dtype, out)
+            self.mid_attn_block.pack("mid_attn_block.", dtype, out)
+            for i in range(self.stages):
+                out[f"down_blocks.{i}.down.w"] = engine.pack_conv_weight(self.down_blocks[i][self.res_blocks].weight, dtype)
+                out[f"up_blocks.{i}.up.w"] = engine.pack_conv_weight(self.up_blocks[i][self.res_blocks].weight, dtype)
+            w = torch.cat([blk.embed_proj.weight.detach().reshape(blk.out_c, -1) for _, blk in self.executed_resblocks()])
+            out["embed_proj.w"] = w.float().contiguous()
+            out["embed_proj.w_time"] = w[:, :128].float().contiguous()
+            out["embed_proj.w_attr"] = w[:, 128:].float().contiguous()
+            out["embed_proj.b"] = torch.cat([blk.embed_proj.bias.detach() for _, blk in self.executed_resblocks()]).float().contiguous()
+        if hit is not None:
+            # programs hold raw pointers into the old packed tensors
+            self._programs = {k: v for k, v in self._programs.items() if k[2] != dtype}
+        self._packed[dtype] = (ver, out)
+        return out
+
+    def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> UNetProgram:
+        dtype = self.compute_dtype if dtype is None else dtype
+        self.packed_weights(dtype)  # refresh (drops stale programs) before the cache lookup
+        key = (B, L, dtype, device, split_embed)
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = UNetProgram(self, B, L, dtype, device, split_embed)
+            self._programs[key] = prog
+        return prog
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._packed.clear()
+        self._programs.clear()
+        return self
+
+    def time_bias_table(self, t_values: torch.Tensor) -> torch.Tensor:
+        """(len(t_values), embed_cols) fp32 rows W_e[:, :128] . swish(time_embed(t)) for the sampler's step table."""
+        n = t_values.numel()
+        dev = t_values.device
+        packed = self.packed_weights(self.compute_dtype)
+        pg = engine.Program(dev, torch.float32)
+        cat = torch.zeros((n, 5), dtype=torch.int64, device=dev)
+        num = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        emb = pg.alloc((n, 256), torch.float32)
+        engine.emit_embed(pg, self.embed_block, packed, n, t_values.to(torch.int64).contiguous(), cat, num, err, emb, want_attr=False)
+        table = torch.empty((n, self.embed_cols), dtype=torch.float32, device=dev)
+        pg.conv([engine.Seg(emb, 256, 128, 1, taps=1)], packed["embed_proj.w_time"], None, table, self.embed_cols, n, 1, self.embed_cols,
+                dtype_code=_lib.TDX_F32, name="embed_proj.time")
+        pg.run()
+        engine.check_err_flag(err, "TrajUNet.time_bias_table")
+        return table
+
+    # ---- the reference's forward ----------------------------------------------------------------
+    def forward(self, x: torch.Tensor, time: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor) -> torch.Tensor:
+        self._guard(x, time, cat_attr, num_attr)
+        if x.dim() != 3 or x.shape[1] != 2:
+            raise TdxError(f"TrajUNet.forward: x must be (B, 2, L), got {tuple(x.shape)}")
+        B, _, L = x.shape
+        prog = self.program(B, L, x.device)
+        prog.load_inputs(x, time, cat_attr, num_attr)
+        prog.run()
+        engine.check_err_flag(prog.err, "TrajUNet.forward")
+        return prog.eps.clone()

@@ -1,0 +1,15 @@
+"""trajectorydiffusion_amd — MI355X-native TrajUNet denoising hot path.
+
+Drop-in for the reference's hot-path objects (same names, signatures and state_dict keys):
+
+    from trajectorydiffusion_amd import TrajUNet, DiffusionManager, DidiTrajectoryDataset, collectFunc
+
+All arithmetic runs in hand-written gfx950 HIP kernels (libtrajdiff_hip.so, C ABI in
+include/trajdiff_hip.h).  There is no CPU / PyTorch fallback for the hot path.
+"""
+from .Models.TrajUNet import TrajUNet  # noqa: F401
+from .Models.TrajUNetBlocks import AttnBlock, ResnetBlock, WideAndDeepEmbedBlock  # noqa: F401
+from .DiffusionManager import DiffusionManager  # noqa: F401
+from .Dataset.DidiDataset import DidiTrajectoryDataset, collectFunc  # noqa: F401
+
+__all__ = ["TrajUNet", "AttnBlock", "ResnetBlock", "WideAndDeepEmbedBlock", "DiffusionManager", "DidiTrajectoryDataset", "collectFunc"]

@@ -1,0 +1,117 @@
+// GroupNorm (+ Swish) over channels-last rows: one wavefront per (trajectory, channel window).
+//
+// A window is W = LPR * (16 B / sizeof(T)) consecutive channels (>= one whole group); the wave
+// sweeps the trajectory's L rows, 64/LPR rows per iteration, 16 bytes per lane, and reduces
+// with wavefront xor-shuffles (no LDS, no atomics).  Statistics are exact two-pass
+// (mean, then centred sum of squares) in fp32.
+#include "tdx_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int out_ld,
+                                                           int out_off, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int B, int L, int C, int cpg,
+                                                           int lpr, float eps, int act) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int H = VEC / 2;
+  const int lane = threadIdx.x & 63;
+  const int W = lpr * VEC;
+  const int wins = C / W;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long)B * wins) return;  // wave-uniform
+  const int b = (int)(wid / wins), win = (int)(wid % wins);
+  const int col = lane % lpr, rl = lane / lpr, rpi = 64 / lpr;
+  const int ch = win * W + col * VEC;
+  const T* xb = x + ((size_t)b * L) * x_ld + ch;
+  const bool split = cpg < VEC;  // two groups inside one 16-byte vector (cpg == VEC/2)
+
+  auto group_sum = [&](float& lo, float& hi) {
+    for (int o = 32; o >= lpr; o >>= 1) {
+      lo += __shfl_xor(lo, o, 64);
+      hi += __shfl_xor(hi, o, 64);
+    }
+    if (!split) {
+      lo += hi;
+      for (int o = 1; o * VEC < cpg; o <<= 1) lo += __shfl_xor(lo, o, 64);
+      hi = lo;
+    }
+  };
+
+  const float inv_cnt = 1.0f / ((float)cpg * (float)L);
+  float s_lo = 0.f, s_hi = 0.f;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      s_lo += v[j];
+      s_hi += v[H + j];
+    }
+  }
+  group_sum(s_lo, s_hi);
+  const float m_lo = s_lo * inv_cnt, m_hi = s_hi * inv_cnt;
+
+  float q_lo = 0.f, q_hi = 0.f;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      float a = v[j] - m_lo, c = v[H + j] - m_hi;
+      q_lo += a * a;
+      q_hi += c * c;
+    }
+  }
+  group_sum(q_lo, q_hi);
+  const float r_lo = rsqrtf(q_lo * inv_cnt + eps), r_hi = rsqrtf(q_hi * inv_cnt + eps);
+
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float g = gamma[ch + j], bt = beta[ch + j];
+    const float r = j < H ? r_lo : r_hi, m = j < H ? m_lo : m_hi;
+    sc[j] = r * g;
+    sh[j] = bt - m * r * g;
+  }
+  T* ob = out + ((size_t)b * L) * out_ld + out_off + ch;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = tdx_act(fmaf(v[j], sc[j], sh[j]), act);
+    *reinterpret_cast<u32x4*>(ob + (size_t)l * out_ld) = Elem<T>::pack(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
+                                 const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
+                                 int32_t groups, float eps, int32_t act, int32_t dtype, void* stream) {
+  TDX_CHECK_ARG(x && out && gamma && beta, "tdx_groupnorm_act: null pointer");
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_groupnorm_act: bad dtype %d", dtype);
+  TDX_CHECK_ARG(B > 0 && L > 0 && C > 0 && groups > 0 && C % groups == 0, "tdx_groupnorm_act: bad shape B=%d L=%d C=%d groups=%d", B, L, C, groups);
+  TDX_CHECK_ARG(act == TDX_ACT_NONE || act == TDX_ACT_SWISH || act == TDX_ACT_LEAKY, "tdx_groupnorm_act: bad act %d", act);
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  const int cpg = C / groups;
+  if (cpg < 4 || (cpg & (cpg - 1)) != 0)
+    TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act: channels per group = %d; need a power of two >= 4", cpg);
+  int lpr = 8;
+  while (lpr * vec < cpg) lpr <<= 1;
+  if (lpr > 64 || C % (lpr * vec) != 0)
+    TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act: C=%d not a multiple of the %d-channel window", C, lpr * vec);
+  TDX_CHECK_ARG(x_ld % vec == 0 && out_ld % vec == 0 && out_off % vec == 0 && x_ld >= C && out_off + C <= out_ld,
+                "tdx_groupnorm_act: x_ld/out_ld/out_off must be multiples of %d and fit", vec);
+  const long waves = (long)B * (C / (lpr * vec));
+  dim3 grid((unsigned)((waves + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDX_F32)
+    hipLaunchKernelGGL(groupnorm_act_kernel<float>, grid, dim3(256), 0, st, (const float*)x, x_ld, (float*)out, out_ld, out_off,
+                       gamma, beta, B, L, C, cpg, lpr, eps, act);
+  else
+    hipLaunchKernelGGL(groupnorm_act_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, x_ld, (__bf16*)out, out_ld,
+                       out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
+  TDX_CHECK_LAUNCH("groupnorm_act_kernel");
+  return TDX_OK;
+}

@@ -1,0 +1,83 @@
+// Shared device/host helpers for the TrajUNet hot-path kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trajdiff_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define TDX_WAVE 64
+
+// ---- error plumbing (no exceptions across the C ABI) ---------------------------------------
+void tdx_set_error(const char* fmt, ...);
+#define TDX_FAIL(code, ...)      \
+  do {                           \
+    tdx_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+#define TDX_CHECK_ARG(cond, ...) \
+  do {                           \
+    if (!(cond)) TDX_FAIL(TDX_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+#define TDX_CHECK_LAUNCH(name)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) TDX_FAIL(TDX_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- element traits -----------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int kVec = 4;  // elements per 16-byte vector
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void unpack(const u32x4& v, float (&o)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(v[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&o)[4]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(o[i]);
+    return v;
+  }
+};
+template <>
+struct Elem<__bf16> {
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float ld(const __bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void unpack(const u32x4& v, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(v[i] << 16);
+      o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&o)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __bf16 lo = (__bf16)o[2 * i], hi = (__bf16)o[2 * i + 1];  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+      v[i] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    return v;
+  }
+};
+
+__device__ __forceinline__ float tdx_swish(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tdx_leaky(float x) { return x > 0.f ? x : 0.1f * x; }
+__device__ __forceinline__ float tdx_act(float x, int act) {
+  return act == TDX_ACT_SWISH ? tdx_swish(x) : (act == TDX_ACT_LEAKY ? tdx_leaky(x) : x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,240 @@
+"""Host-side executor for the TrajUNet hot path: turns a TrajUNet (parameters only) plus a
+(batch, length, dtype) into a static *program* — a flat list of C-ABI kernel launches over
+pre-allocated channels-last workspaces — that can be run eagerly or captured into a HIP graph.
+
+PyTorch is used for device memory, streams and graph capture only; every arithmetic op of
+the path is a call into libtrajdiff_hip.so (trajectorydiffusion_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_SWISH, ConvDesc, TdxError
+
+
+def conv_out_len(l: int, stride: int) -> int:
+    """Conv1d(k=3, p=1, stride) output length (Models/TrajUNet.py:52)."""
+    return (l - 1) // stride + 1
+
+
+def nearest_map(l_in: int, l_out: int) -> torch.Tensor:
+    """F.interpolate(mode='nearest', size=l_out) source rows (Models/TrajUNet.py:93), int32 on CPU.
+
+    ATen: src = min(floor(dst * float32(l_in / l_out)), l_in - 1).
+    """
+    scale = torch.tensor(l_in / l_out, dtype=torch.float32)
+    idx = torch.floor(torch.arange(l_out, dtype=torch.float32) * scale).to(torch.int32)
+    return idx.clamp_(max=l_in - 1)
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(Cout, Cin, k) -> (Cout, k*Cin) with K order (tap, channel), cast to the compute dtype."""
+    return w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+
+
+class Seg:
+    """One K-segment of a gathered GEMM (see tdx_kseg in include/trajdiff_hip.h)."""
+    __slots__ = ("src", "ld", "ch_off", "cin", "taps", "stride", "lin", "lvirt", "upmap")
+
+    def __init__(self, src: torch.Tensor, ld: int, cin: int, lin: int, taps: int = 3, stride: int = 1, ch_off: int = 0,
+                 upmap: Optional[torch.Tensor] = None, lvirt: Optional[int] = None):
+        self.src, self.ld, self.ch_off, self.cin, self.taps, self.stride = src, ld, ch_off, cin, taps, stride
+        self.lin, self.upmap = lin, upmap
+        self.lvirt = lin if lvirt is None else lvirt
+
+
+class Program:
+    """A recorded sequence of C-ABI launches.  `run()` replays them on the current stream."""
+
+    def __init__(self, device: torch.device, dtype: torch.dtype):
+        self.device, self.dtype = device, dtype
+        self.code = _lib.dtype_code(dtype)
+        self.lib = _lib.lib()
+        self.ops: List[Tuple] = []
+        self.keep: List = []  # tensors / descriptors referenced by raw pointer
+        self._pool: Dict[Tuple[int, torch.dtype], List[torch.Tensor]] = {}
+
+    # ---- workspace -------------------------------------------------------------------------
+    def alloc(self, shape: Sequence[int], dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        dtype = self.dtype if dtype is None else dtype
+        n = 1
+        for s in shape:
+            n *= int(s)
+        free = self._pool.get((n, dtype))
+        if free:
+            return free.pop().view(*shape)
+        t = torch.empty(n, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t.view(*shape)
+
+    def release(self, t: torch.Tensor) -> None:
+        """Return a workspace to the pool: later ops of the program may overwrite it."""
+        self._pool.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
+
+    # ---- op recording ----------------------------------------------------------------------
+    def _add(self, name: str, fn, *args) -> None:
+        self.ops.append((name, fn, args))
+
+    def conv(self, segs: Sequence[Seg], w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, out_ld: int,
+             B: int, lout: int, cout: int, out_off: int = 0, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+             res_ld: int = 0, ebias: Optional[torch.Tensor] = None, tbias: Optional[torch.Tensor] = None, ebias_ld: int = 0,
+             ebias_off: int = 0, dtype_code: Optional[int] = None, name: str = "conv") -> None:
+        d = ConvDesc()
+        ktot = 0
+        for i, s in enumerate(segs):
+            k = d.seg[i]
+            k.src, k.upmap = s.src.data_ptr(), (s.upmap.data_ptr() if s.upmap is not None else None)
+            k.src_ld, k.ch_off, k.cin, k.taps, k.stride, k.lin, k.lvirt = s.ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt
+            ktot += s.taps * s.cin
+            self.keep.append(s.src)
+            if s.upmap is not None:
+                self.keep.append(s.upmap)
+        if tuple(w.shape) != (cout, ktot):
+            raise TdxError(f"{name}: packed weight is {tuple(w.shape)}, segments need ({cout}, {ktot})")
+        d.nseg, d.dtype = len(segs), self.code if dtype_code is None else dtype_code
+        d.w, d.bias = w.data_ptr(), _lib.ptr(bias)
+        d.ebias, d.tbias, d.ebias_ld, d.ebias_off = _lib.ptr(ebias), _lib.ptr(tbias), ebias_ld, ebias_off
+        d.res, d.res_ld, d.act = _lib.ptr(res), res_ld, act
+        d.out, d.out_ld, d.out_off = out.data_ptr(), out_ld, out_off
+        d.B, d.lout, d.cout = B, lout, cout
+        self.keep.extend([d, w, bias, out, res, ebias, tbias])
+        self._add(name, self.lib.tdx_conv_gemm, C.byref(d))
+
+    def groupnorm(self, x: torch.Tensor, x_ld: int, out: torch.Tensor, out_ld: int, out_off: int, gamma: torch.Tensor,
+                  beta: torch.Tensor, p_off: int, B: int, L: int, Cn: int, groups: int, eps: float, act: int,
+                  name: str = "gn") -> None:
+        self.keep.extend([x, out, gamma, beta])
+        self._add(name, self.lib.tdx_groupnorm_act, x.data_ptr(), x_ld, out.data_ptr(), out_ld, out_off,
+                  gamma.data_ptr() + 4 * p_off, beta.data_ptr() + 4 * p_off, B, L, Cn, groups, eps, act, self.code)
+
+    def call(self, name: str, fn, *args, keep: Sequence = ()) -> None:
+        self.keep.extend(keep)
+        self._add(name, fn, *args)
+
+    # ---- execution -------------------------------------------------------------------------
+    def run(self) -> None:
+        st = _lib.stream_ptr()
+        for name, fn, args in self.ops:
+            rc = fn(*args, st)
+            if rc:
+                _lib.check(rc, name)
+
+
+def fp32_param(p: torch.Tensor, name: str) -> torch.Tensor:
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        raise TdxError(f"parameter {name} must be contiguous fp32 (got {p.dtype}); keep master weights in fp32")
+    return p.detach()
+
+
+class ResSpec:
+    """Everything the executor needs from one ResnetBlock (parameters by reference)."""
+
+    def __init__(self, blk, e_off: int):
+        self.blk, self.e_off = blk, e_off
+        self.cin, self.cout = blk.in_c, blk.out_c
+
+
+def emit_resblock(pg: Program, blk, packed: Dict[str, torch.Tensor], key: str, srcs: Sequence[Tuple[torch.Tensor, int]],
+                  B: int, L: int, ebias: Optional[torch.Tensor], tbias: Optional[torch.Tensor], e_ld: int, e_off: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ResnetBlock (Models/TrajUNetBlocks.py:92-99) over channels-last sources.
+
+    `srcs` is [(tensor (B, L, C_k), C_k), ...]: more than one entry is the decoder's channel concat
+    (Models/TrajUNet.py:90), which is never materialised for the raw tensor: GroupNorm writes its
+    activated output into one concatenated buffer and the 1x1 shortcut reads each source as its
+    own K-segment.
+    """
+    cin = sum(c for _, c in srcs)
+    cout = blk.out_c
+    if cin != blk.in_c:
+        raise TdxError(f"{key}: sources carry {cin} channels, block expects {blk.in_c}")
+    groups = blk.norm_groups
+    cpg = cin // groups
+    gn1, conv1 = blk.stage1[0], blk.stage1[2]
+    gn2, conv2 = blk.stage2[0], blk.stage2[3]
+    a1 = pg.alloc((B, L, cin))
+    off = 0
+    for src, c in srcs:
+        if c % cpg:
+            raise TdxError(f"{key}: concat boundary at channel {off + c} splits a GroupNorm group of {cpg}")
+        pg.groupnorm(src, c, a1, cin, off, fp32_param(gn1.weight, key + "stage1.0.weight"), fp32_param(gn1.bias, key + "stage1.0.bias"),
+                     off, B, L, c, c // cpg, gn1.eps, ACT_SWISH, name=key + "gn1")
+        off += c
+    h = pg.alloc((B, L, cout))
+    pg.conv([Seg(a1, cin, cin, L)], packed[key + "conv1.w"], fp32_param(conv1.bias, key + "stage1.2.bias"), h, cout, B, L, cout,
+            ebias=ebias, tbias=tbias, ebias_ld=e_ld, ebias_off=e_off, name=key + "conv1")
+    pg.release(a1)
+    a2 = pg.alloc((B, L, cout))
+    pg.groupnorm(h, cout, a2, cout, 0, fp32_param(gn2.weight, key + "stage2.0.weight"), fp32_param(gn2.bias, key + "stage2.0.bias"),
+                 0, B, L, cout, groups, gn2.eps, ACT_SWISH, name=key + "gn2")
+    pg.release(h)
+    if out is None:
+        out = pg.alloc((B, L, cout))
+    segs = [Seg(a2, cout, cout, L)]
+    if blk.has_shortcut:
+        segs += [Seg(src, c, c, L, taps=1) for src, c in srcs]
+        pg.conv(segs, packed[key + "conv2.w"], packed[key + "conv2.b"], out, cout, B, L, cout, name=key + "conv2")
+    else:
+        pg.conv(segs, packed[key + "conv2.w"], fp32_param(conv2.bias, key + "stage2.3.bias"), out, cout, B, L, cout,
+                res=srcs[0][0], res_ld=cin, name=key + "conv2")
+    pg.release(a2)
+    return out
+
+
+def pack_resblock(blk, key: str, dtype: torch.dtype, out: Dict[str, torch.Tensor]) -> None:
+    out[key + "conv1.w"] = pack_conv_weight(blk.stage1[2].weight, dtype)
+    w2 = pack_conv_weight(blk.stage2[3].weight, dtype)
+    if blk.has_shortcut:
+        out[key + "conv2.w"] = torch.cat([w2, pack_conv_weight(blk.shortcut.weight, dtype)], dim=1).contiguous()
+        out[key + "conv2.b"] = (blk.stage2[3].bias.detach() + blk.shortcut.bias.detach()).float().contiguous()
+    else:
+        out[key + "conv2.w"] = w2
+
+
+def emit_embed(pg: Program, emb, packed: Dict[str, torch.Tensor], B: int, time: torch.Tensor, cat: torch.Tensor,
+               num: torch.Tensor, err: torch.Tensor, emb_out: torch.Tensor, want_time: bool = True,
+               want_attr: bool = True) -> None:
+    """WideAndDeepEmbedBlock.forward (Models/TrajUNetBlocks.py:45-62): emb_out (B, 256) fp32 =
+    swish([time_embed | attr_embed]).  All fp32 regardless of the UNet compute dtype."""
+    f32 = torch.float32
+    pe = pg.alloc((B, 128), f32)
+    catvec = pg.alloc((B, 1280), f32)
+    deep_in = pg.alloc((B, 1024), f32)
+    pg.call("embed_gather", pg.lib.tdx_embed_gather, time.data_ptr(), cat.data_ptr(), num.data_ptr(), emb.pos_enc.data_ptr(),
+            emb.pos_enc.shape[0], fp32_param(emb.cell_index_embedder.weight, "cell").data_ptr(),
+            fp32_param(emb.day_embedder.weight, "day").data_ptr(), fp32_param(emb.wide_fc.weight, "wide_w").data_ptr(),
+            fp32_param(emb.wide_fc.bias, "wide_b").data_ptr(), pe.data_ptr(), catvec.data_ptr(), deep_in.data_ptr(), B,
+            err.data_ptr(), keep=[time, cat, num, emb.pos_enc, err])
+    F32 = _lib.TDX_F32
+
+    def lin(src, k, w, b, out, out_ld, n, off, act, name):
+        pg.conv([Seg(src, k, k, 1, taps=1)], w, b, out, out_ld, B, 1, n, out_off=off, act=act, dtype_code=F32, name=name)
+
+    if want_time:
+        t0, t2 = emb.time_embed_layers[0], emb.time_embed_layers[2]
+        h1 = pg.alloc((B, 128), f32)
+        lin(pe, 128, fp32_param(t0.weight, "t0.w"), fp32_param(t0.bias, "t0.b"), h1, 128, 128, 0, ACT_LEAKY, "embed.time0")
+        lin(h1, 128, fp32_param(t2.weight, "t2.w"), fp32_param(t2.bias, "t2.b"), emb_out, 256, 128, 0, ACT_SWISH, "embed.time2")
+        pg.release(h1)
+    if want_attr:
+        cf, d1, d3 = emb.categorical_fc, emb.deep_fc[1], emb.deep_fc[3]
+        lin(catvec, 1280, fp32_param(cf.weight, "cf.w"), fp32_param(cf.bias, "cf.b"), deep_in, 1024, 768, 0, ACT_LEAKY, "embed.cat_fc")
+        hd = pg.alloc((B, 512), f32)
+        lin(deep_in, 1024, fp32_param(d1.weight, "d1.w"), fp32_param(d1.bias, "d1.b"), hd, 512, 512, 0, ACT_LEAKY, "embed.deep1")
+        lin(hd, 512, fp32_param(d3.weight, "d3.w"), fp32_param(d3.bias, "d3.b"), emb_out, 256, 128, 128, ACT_SWISH, "embed.deep3")
+        pg.release(hd)
+    for t in (pe, catvec, deep_in):
+        pg.release(t)
+
+
+def check_err_flag(err: torch.Tensor, what: str) -> None:
+    code = int(err.item())
+    if code:
+        err.zero_()
+        msgs = [m for bit, m in ((1, "time step out of [0, diffusion_steps)"), (2, "categorical attribute index out of range"),
+                                 (4, "q_sample time step out of range")) if code & bit]
+        raise IndexError(f"{what}: " + "; ".join(msgs))

@@ -175,7 +175,8 @@ def test_attention(dt, B, L, C):
     qv, kv, vv = torch.split(qq, C, dim=2)
     ref = torch.bmm(torch.softmax(torch.bmm(qv, kv.transpose(1, 2)) / C ** 0.5, dim=2), vv)
     out = torch.empty((B, L, C), device="cuda", dtype=dt)
-    _lib.check(_lib.lib().tdx_attention(qkv.to("cuda", dt).data_ptr(), out.data_ptr(), B, L, C, _lib.dtype_code(dt), _lib.stream_ptr()))
+    qd = qkv.to("cuda", dt)
+    _lib.check(_lib.lib().tdx_attention(qd.data_ptr(), out.data_ptr(), B, L, C, _lib.dtype_code(dt), _lib.stream_ptr()))
     assert rel(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 1e-2)
 
 
@@ -189,13 +190,15 @@ def test_stem_and_head(dt, L):
     w, b = torch.randn(C0, 2, 3, generator=g), torch.randn(C0, generator=g)
     out = torch.empty((B, L, C0), device="cuda", dtype=dt)
     code = _lib.dtype_code(dt)
-    _lib.check(_lib.lib().tdx_stem_conv(x.cuda().data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(), out.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()  # keep the device copies alive while raw pointers are in flight
+    _lib.check(_lib.lib().tdx_stem_conv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
     ref = F.conv1d(x, w, b, padding=1)
     assert rel(unrows(out), ref) < (1e-6 if dt == torch.float32 else 5e-3)
     a = torch.randn(B, C0, L, generator=g)
     wh, bh = torch.randn(2, C0, 3, generator=g) / 20, torch.randn(2, generator=g)
     eps = torch.empty((B, 2, L), device="cuda")
-    _lib.check(_lib.lib().tdx_head_conv(rows(a, dt).data_ptr(), wh.cuda().data_ptr(), bh.cuda().data_ptr(), eps.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
+    ad, whd, bhd = rows(a, dt), wh.cuda(), bh.cuda()
+    _lib.check(_lib.lib().tdx_head_conv(ad.data_ptr(), whd.data_ptr(), bhd.data_ptr(), eps.data_ptr(), B, L, C0, code, _lib.stream_ptr()))
     assert rel(eps.cpu(), F.conv1d(q(a, dt), wh, bh, padding=1)) < 2e-5
 
 

@@ -55,6 +55,7 @@ class Program:
         self.code = _lib.dtype_code(dtype)
         self.lib = _lib.lib()
         self.ops: List[Tuple] = []
+        self.flops: Dict[int, float] = {}  # op index -> algorithmic FLOPs (GEMM ops only)
         self.keep: List = []  # tensors / descriptors referenced by raw pointer
         self._pool: Dict[Tuple[int, torch.dtype], List[torch.Tensor]] = {}
 
@@ -103,6 +104,7 @@ class Program:
         d.B, d.lout, d.cout = B, lout, cout
         self.keep.extend([d, w, bias, out, res, ebias, tbias])
         self._add(name, self.lib.tdx_conv_gemm, C.byref(d))
+        self.flops[len(self.ops) - 1] = 2.0 * B * lout * cout * ktot
 
     def groupnorm(self, x: torch.Tensor, x_ld: int, out: torch.Tensor, out_ld: int, out_off: int, gamma: torch.Tensor,
                   beta: torch.Tensor, p_off: int, B: int, L: int, Cn: int, groups: int, eps: float, act: int,
@@ -122,6 +124,21 @@ class Program:
             rc = fn(*args, st)
             if rc:
                 _lib.check(rc, name)
+
+    def profile(self, repeats: int = 3):
+        """Per-op device time (ms, best of `repeats`) from HIP events on the launch stream."""
+        st = _lib.stream_ptr()
+        best = [float("inf")] * len(self.ops)
+        for _ in range(repeats):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.ops) + 1)]
+            evs[0].record()
+            for i, (name, fn, args) in enumerate(self.ops):
+                _lib.check(fn(*args, st), name)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            for i in range(len(self.ops)):
+                best[i] = min(best[i], evs[i].elapsed_time(evs[i + 1]))
+        return [(self.ops[i][0], self.ops[i][1].__name__, best[i], self.flops.get(i, 0.0)) for i in range(len(self.ops))]
 
 
 def fp32_param(p: torch.Tensor, name: str) -> torch.Tensor:

@@ -75,8 +75,15 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wc = wave & 1, wr = wave >> 1;
-  const int co0 = blockIdx.x * TC;
-  const int n0 = blockIdx.y * TR;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so ids that are equal mod 8 share
+  // an L2.  Give each of those 8 streams its own row tiles and let it walk all channel tiles of a row tile
+  // back to back: an activation tile is then fetched into ONE L2 and re-used there by every channel tile.
+  const int nco = (p.cout + TC - 1) / TC;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int row_tile = (j / nco) * 8 + xcd;
+  const int n0 = row_tile * TR;
+  if (n0 >= p.N) return;  // block-uniform: padding blocks of the last group of 8 row tiles
+  const int co0 = (j % nco) * TC;
 
   // ---- staging role: 16-byte chunk c of rows rbase + 32*i -----------------------------------
   const int c = tid & 7, rbase = tid >> 3;
@@ -251,12 +258,14 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
 
 template <typename T, int TR, int TC>
 int launch(const ConvArgs& a, hipStream_t st) {
-  dim3 grid((a.cout + TC - 1) / TC, (a.N + TR - 1) / TR);
+  const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + TR - 1) / TR;
+  dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
   size_t lds = 2 * (size_t)(TR + TC) * kRowBytes;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TR, TC>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TR, TC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      TDX_FAIL(TDX_ERR_HIP, "conv_gemm: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
   hipLaunchKernelGGL((conv_gemm_kernel<T, TR, TC>), grid, dim3(kThreads), lds, st, a);

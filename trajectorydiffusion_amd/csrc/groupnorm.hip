@@ -8,13 +8,15 @@
 
 namespace {
 
-template <typename T>
+// NIT = row iterations per lane kept in registers (0: re-read the rows from L2 in each of the three sweeps).
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int out_ld,
                                                            int out_off, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int B, int L, int C, int cpg,
                                                            int lpr, float eps, int act) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = VEC / 2;
+  constexpr int NR = NIT > 0 ? NIT : 1;
   const int lane = threadIdx.x & 63;
   const int W = lpr * VEC;
   const int wins = C / W;
@@ -38,11 +40,28 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
     }
   };
 
+  u32x4 held[NR];
+  if constexpr (NIT > 0) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int l = rl + i * rpi;
+      held[i] = l < L ? *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  auto row = [&](int i, int l) -> u32x4 {
+    if constexpr (NIT > 0) return held[i];
+    else return *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld);
+  };
+  const int nit = NIT > 0 ? NIT : (L - rl + rpi - 1) / rpi;
+
   const float inv_cnt = 1.0f / ((float)cpg * (float)L);
   float s_lo = 0.f, s_hi = 0.f;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = rl + i * rpi;
+    if (l >= L) break;
     float v[VEC];
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+    Elem<T>::unpack(row(i, l), v);
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       s_lo += v[j];
@@ -53,9 +72,12 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
   const float m_lo = s_lo * inv_cnt, m_hi = s_hi * inv_cnt;
 
   float q_lo = 0.f, q_hi = 0.f;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = rl + i * rpi;
+    if (l >= L) break;
     float v[VEC];
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+    Elem<T>::unpack(row(i, l), v);
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       float a = v[j] - m_lo, c = v[H + j] - m_hi;
@@ -75,13 +97,31 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
     sh[j] = bt - m * r * g;
   }
   T* ob = out + ((size_t)b * L) * out_ld + out_off + ch;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = rl + i * rpi;
+    if (l >= L) break;
     float v[VEC];
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+    Elem<T>::unpack(row(i, l), v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = tdx_act(fmaf(v[j], sc[j], sh[j]), act);
     *reinterpret_cast<u32x4*>(ob + (size_t)l * out_ld) = Elem<T>::pack(v);
   }
+}
+
+template <typename T>
+void launch_gn(int nit, dim3 grid, hipStream_t st, const void* x, int x_ld, void* out, int out_ld, int out_off, const float* gamma,
+               const float* beta, int B, int L, int C, int cpg, int lpr, float eps, int act) {
+#define TDX_GN(N)                                                                                                              \
+  hipLaunchKernelGGL((groupnorm_act_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, x_ld, (T*)out, out_ld, out_off, gamma, \
+                     beta, B, L, C, cpg, lpr, eps, act)
+  if (nit <= 2) TDX_GN(2);
+  else if (nit <= 4) TDX_GN(4);
+  else if (nit <= 8) TDX_GN(8);
+  else if (nit <= 16) TDX_GN(16);
+  else if (nit <= 26) TDX_GN(26);
+  else TDX_GN(0);
+#undef TDX_GN
 }
 
 }  // namespace
@@ -106,12 +146,11 @@ extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t
   const long waves = (long)B * (C / (lpr * vec));
   dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
+  const int nit = (L + 64 / lpr - 1) / (64 / lpr);
   if (dtype == TDX_F32)
-    hipLaunchKernelGGL(groupnorm_act_kernel<float>, grid, dim3(256), 0, st, (const float*)x, x_ld, (float*)out, out_ld, out_off,
-                       gamma, beta, B, L, C, cpg, lpr, eps, act);
+    launch_gn<float>(nit, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   else
-    hipLaunchKernelGGL(groupnorm_act_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, x_ld, (__bf16*)out, out_ld,
-                       out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
+    launch_gn<__bf16>(nit, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   TDX_CHECK_LAUNCH("groupnorm_act_kernel");
   return TDX_OK;
 }

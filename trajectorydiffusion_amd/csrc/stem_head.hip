@@ -4,71 +4,105 @@
 
 namespace {
 
-// one thread = one (row, 16-byte channel vector); x is (B, 2, L) fp32 channels-first.
+// Each thread owns one 16-byte channel vector (its 6*VEC weights stay in registers) and walks rows;
+// x is (B, 2, L) fp32 channels-first.  A wave writes whole contiguous row segments.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, T* __restrict__ out, int B, int L, int C0) {
+                                                       const float* __restrict__ bias, T* __restrict__ out, int B, int L, int C0,
+                                                       int rows_per_block) {
   constexpr int VEC = Elem<T>::kVec;
-  const int vpr = C0 / VEC;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)B * L * vpr) return;
-  const int cv = (int)(gid % vpr);
-  const long n = gid / vpr;
-  const int b = (int)(n / L), l = (int)(n % L);
-  const float* xb = x + (size_t)b * 2 * L;
-  float xin[2][3];
+  const int vpr = C0 / VEC;                    // vectors per row; host guarantees 256 % vpr == 0 or vpr % 256 == 0
+  const int tpr = vpr < 256 ? vpr : 256;       // threads that share one row at a time
+  const int rstep = 256 / tpr;
+  const long nrows = (long)B * L;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  for (int cv = threadIdx.x % tpr; cv < vpr; cv += 256) {
+    float wr[VEC][6], bs[VEC];
 #pragma unroll
-  for (int ci = 0; ci < 2; ++ci)
+    for (int j = 0; j < VEC; ++j) {
+      bs[j] = bias[cv * VEC + j];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int u = l + t - 1;
-      xin[ci][t] = (u >= 0 && u < L) ? xb[ci * L + u] : 0.f;
+      for (int k = 0; k < 6; ++k) wr[j][k] = w[(cv * VEC + j) * 6 + k];
     }
-  float v[VEC];
+    for (int rr = threadIdx.x / tpr; rr < rows_per_block; rr += rstep) {
+      const long n = r0 + rr;
+      if (n >= nrows) break;
+      const int b = (int)(n / L), l = (int)(n % L);
+      const float* xb = x + (size_t)b * 2 * L;
+      float xin[6];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    const int co = cv * VEC + j;
-    float a = bias[co];
+      for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) a = fmaf(w[(co * 2 + ci) * 3 + t], xin[ci][t], a);
-    v[j] = a;
-  }
-  *reinterpret_cast<u32x4*>(out + (size_t)n * C0 + cv * VEC) = Elem<T>::pack(v);
-}
-
-// One wavefront per output row: lanes split the channels (16-byte vectors), each accumulates the
-// row's contribution to out[l-1] (tap 2), out[l] (tap 1), out[l+1] (tap 0) ... instead we gather:
-// out[b, o, l] = bias[o] + sum_t sum_c w[o, c, t] * a[b, l+t-1, c]; lanes split c, then a wave reduction.
-template <typename T>
-__global__ __launch_bounds__(256) void head_conv_kernel(const T* __restrict__ a, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int L, int C0) {
-  constexpr int VEC = Elem<T>::kVec;
-  const int lane = threadIdx.x & 63;
-  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= (long)B * L) return;  // wave-uniform
-  const int b = (int)(n / L), l = (int)(n % L);
-  float acc0 = 0.f, acc1 = 0.f;
-  for (int c0 = lane * VEC; c0 < C0; c0 += 64 * VEC) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int u = l + t - 1;
-      if (u < 0 || u >= L) continue;  // wave-uniform
+        for (int t = 0; t < 3; ++t) {
+          const int u = l + t - 1;
+          xin[ci * 3 + t] = (u >= 0 && u < L) ? xb[ci * L + u] : 0.f;
+        }
       float v[VEC];
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(a + ((size_t)b * L + u) * C0 + c0), v);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        acc0 = fmaf(w[(0 * C0 + c0 + j) * 3 + t], v[j], acc0);
-        acc1 = fmaf(w[(1 * C0 + c0 + j) * 3 + t], v[j], acc1);
+        float a = bs[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a = fmaf(wr[j][k], xin[k], a);
+        v[j] = a;
       }
+      *reinterpret_cast<u32x4*>(out + (size_t)n * C0 + cv * VEC) = Elem<T>::pack(v);
     }
   }
-  acc0 = wave_sum(acc0);
-  acc1 = wave_sum(acc1);
-  if (lane == 0) {
-    out[((size_t)b * 2 + 0) * L + l] = acc0 + bias[0];
-    out[((size_t)b * 2 + 1) * L + l] = acc1 + bias[1];
+}
+
+// LPR lanes share one output row (each owns one 16-byte channel vector and keeps its 6*VEC weights in registers),
+// 64/LPR rows per wavefront iteration, `iters` iterations per wavefront:
+// out[b, o, l] = bias[o] + sum_t sum_c w[o, c, t] * a[b, l+t-1, c], reduced with xor-shuffles inside the row's lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void head_conv_kernel(const T* __restrict__ a, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int L, int C0,
+                                                       int lpr, int iters) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int lane = threadIdx.x & 63;
+  const int col = lane % lpr, rpw = 64 / lpr;
+  const long nrows = (long)B * L;
+  const long wave_row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw * iters;
+  const float b0 = bias[0], b1 = bias[1];
+  for (int cb = col * VEC; cb < C0; cb += lpr * VEC) {  // one pass when lpr * VEC >= C0 (the normal case)
+    const bool first = cb == col * VEC;
+    float w0[3][VEC], w1[3][VEC];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        w0[t][j] = w[(0 * C0 + cb + j) * 3 + t];
+        w1[t][j] = w[(1 * C0 + cb + j) * 3 + t];
+      }
+    for (int it = 0; it < iters; ++it) {
+      const long n = wave_row0 + (long)it * rpw + lane / lpr;
+      const bool live = n < nrows;
+      const int b = live ? (int)(n / L) : 0, l = live ? (int)(n % L) : 0;
+      float acc0 = 0.f, acc1 = 0.f;
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int u = l + t - 1;
+          if (u < 0 || u >= L) continue;
+          float v[VEC];
+          Elem<T>::unpack(*reinterpret_cast<const u32x4*>(a + ((size_t)b * L + u) * C0 + cb), v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            acc0 = fmaf(w0[t][j], v[j], acc0);
+            acc1 = fmaf(w1[t][j], v[j], acc1);
+          }
+        }
+      }
+      for (int o = 1; o < lpr; o <<= 1) {
+        acc0 += __shfl_xor(acc0, o, 64);
+        acc1 += __shfl_xor(acc1, o, 64);
+      }
+      if (live && col == 0) {
+        float* o0 = out + ((size_t)b * 2 + 0) * L + l;
+        float* o1 = out + ((size_t)b * 2 + 1) * L + l;
+        *o0 = first ? acc0 + b0 : *o0 + acc0;
+        *o1 = first ? acc1 + b1 : *o1 + acc1;
+      }
+    }
   }
 }
 
@@ -80,13 +114,17 @@ extern "C" int tdx_stem_conv(const float* x, const float* w, const float* bias, 
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_stem_conv: bad dtype %d", dtype);
   const int vec = dtype == TDX_F32 ? 4 : 8;
   TDX_CHECK_ARG(B > 0 && L > 0 && C0 > 0 && C0 % vec == 0, "tdx_stem_conv: bad shape B=%d L=%d C0=%d", B, L, C0);
-  const long total = (long)B * L * (C0 / vec);
-  dim3 grid((unsigned)((total + 255) / 256));
+  const int vpr = C0 / vec;
+  if (!(256 % vpr == 0 || vpr % 256 == 0))
+    TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_stem_conv: C0=%d gives %d vectors per row; need a divisor or multiple of 256", C0, vpr);
+  const int rows_per_block = 64 * (256 / (vpr < 256 ? vpr : 256));
+  const long rows = (long)B * L;
+  dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDX_F32)
-    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, st, x, w, bias, (float*)out, B, L, C0);
+    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, st, x, w, bias, (float*)out, B, L, C0, rows_per_block);
   else
-    hipLaunchKernelGGL(stem_conv_kernel<__bf16>, grid, dim3(256), 0, st, x, w, bias, (__bf16*)out, B, L, C0);
+    hipLaunchKernelGGL(stem_conv_kernel<__bf16>, grid, dim3(256), 0, st, x, w, bias, (__bf16*)out, B, L, C0, rows_per_block);
   TDX_CHECK_LAUNCH("stem_conv_kernel");
   return TDX_OK;
 }
@@ -98,12 +136,16 @@ extern "C" int tdx_head_conv(const void* a, const float* w, const float* bias, f
   const int vec = dtype == TDX_F32 ? 4 : 8;
   TDX_CHECK_ARG(B > 0 && L > 0 && C0 > 0 && C0 % vec == 0, "tdx_head_conv: bad shape B=%d L=%d C0=%d", B, L, C0);
   const long rows = (long)B * L;
-  dim3 grid((unsigned)((rows + 3) / 4));
+  int lpr = 1;
+  while (lpr < 64 && lpr * vec < C0) lpr <<= 1;  // lanes per row: enough 16-byte vectors to cover C0 in one step if possible
+  const int iters = 16;
+  const long per_block = 4 * (64 / lpr) * iters;
+  dim3 grid((unsigned)((rows + per_block - 1) / per_block));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDX_F32)
-    hipLaunchKernelGGL(head_conv_kernel<float>, grid, dim3(256), 0, st, (const float*)a, w, bias, out, B, L, C0);
+    hipLaunchKernelGGL(head_conv_kernel<float>, grid, dim3(256), 0, st, (const float*)a, w, bias, out, B, L, C0, lpr, iters);
   else
-    hipLaunchKernelGGL(head_conv_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)a, w, bias, out, B, L, C0);
+    hipLaunchKernelGGL(head_conv_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)a, w, bias, out, B, L, C0, lpr, iters);
   TDX_CHECK_LAUNCH("head_conv_kernel");
   return TDX_OK;
 }

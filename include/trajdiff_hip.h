@@ -37,11 +37,13 @@ int tdx_device_ok(void);            /* 0 iff the current device is gfx950 */
 
 /* One K-segment of the implicit GEMM: a (source tensor, taps) pair.  Output row n = (b, l)
  * consumes, for tap t, source row  b*lin + map(l*stride + t - (taps==3))  or zeros when that
- * virtual index falls outside [0, lvirt) — i.e. Conv1d's zero padding.  `upmap` (device int32
- * [lvirt], may be NULL = identity) is F.interpolate(mode='nearest')'s source index table. */
+ * virtual index u falls outside [0, lvirt) — i.e. Conv1d's zero padding.  map is the identity when
+ * lvirt == lin; otherwise it is F.interpolate(mode='nearest', size=lvirt)'s source index, computed
+ * exactly as ATen does: min((int)floorf(u * up_scale), lin - 1) with up_scale = (float)lin / lvirt. */
 typedef struct {
   const void* src;      /* (B, lin, src_ld) activations */
-  const int32_t* upmap; /* NULL or [lvirt] nearest-upsample source rows */
+  float up_scale;       /* (float)lin / (float)lvirt when lvirt != lin, else ignored */
+  int32_t reserved0;
   int32_t src_ld;       /* elements per source row */
   int32_t ch_off;       /* first source channel consumed */
   int32_t cin;          /* channels consumed; multiple of 64 (bf16) / 32 (fp32) */

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of tdx_conv_gemm on the TrajUNet conv shapes at B=4096 (bf16), with ablation bits.
+usage: python scripts/conv_bench.py [--debug BITS] [--small]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajectorydiffusion_amd import _lib, engine  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--debug", type=int, nargs="*", default=[0])
+ap.add_argument("--small", action="store_true")
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+B = a.batch
+SHAPES = [  # (name, L, Cin, Cout, taps)
+    ("128->128@200", 200, 128, 128, 3), ("256->256@100", 100, 256, 256, 3), ("512->512@50", 50, 512, 512, 3),
+    ("1024->1024@25", 25, 1024, 1024, 3), ("1024->1024@13", 13, 1024, 1024, 3), ("2048->512@13", 13, 2048, 512, 3),
+    ("qkv 1024->3072@13", 13, 1024, 3072, 1),
+]
+lib = _lib.lib()
+lib.tdx_conv_gemm_force_small(1 if a.small else 0)
+print(f"{'shape':22s} " + " ".join(f"dbg{d}: ms / TF  " for d in a.debug))
+for name, L, ci, co, k in SHAPES:
+    x = torch.randn((B, L, ci), device="cuda").to(dt)
+    w = (torch.randn((co, k * ci), device="cuda") / (k * ci) ** 0.5).to(dt)
+    bias = torch.randn(co, device="cuda")
+    out = torch.empty((B, L, co), device="cuda", dtype=dt)
+    pg = engine.Program(torch.device("cuda"), dt)
+    pg.conv([engine.Seg(x, ci, ci, L, taps=k)], w, bias, out, co, B, L, co)
+    fl = 2.0 * B * L * co * k * ci
+    cells = []
+    for d in a.debug:
+        lib.tdx_conv_gemm_debug(d)
+        for _ in range(3):
+            pg.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            pg.run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        cells.append(f"{ms:7.3f} / {fl / ms / 1e9:6.0f}")
+    lib.tdx_conv_gemm_debug(0)
+    print(f"{name:22s} " + "   ".join(cells))

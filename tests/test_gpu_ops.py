@@ -42,7 +42,7 @@ def run_conv(dt, x, w, b, stride=1, upmap_to=None, act=0, res=None, ebias=None, 
     src = rows(x, dt)
     if upmap_to is not None:
         lo = upmap_to
-        seg = engine.Seg(src, Ci, Ci, L, taps=w.shape[2], upmap=engine.nearest_map(L, lo).cuda(), lvirt=lo)
+        seg = engine.Seg(src, Ci, Ci, L, taps=w.shape[2], lvirt=lo)
     else:
         lo = (L - 1) // stride + 1 if w.shape[2] == 3 else L
         seg = engine.Seg(src, Ci, Ci, L, taps=w.shape[2], stride=stride)
@@ -130,6 +130,49 @@ def test_conv_concat_plus_shortcut_segments(dt):
     pg.conv(segs, wp, b.cuda(), out, Co, B, L, Co)
     pg.run()
     assert rel(unrows(out), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", ["s1_c128", "s1_c256", "s2", "up", "k1_res", "tail_rows"])
+def test_conv_large_tiles_dma_kernel(dt, case):
+    """Shapes big enough for the 256-row LDS-DMA kernel: checked against F.conv1d AND bit-for-bit against the
+    128x128 register-staged kernel (same K order, same MFMA chain => identical fp32 sums)."""
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(len(case))
+    kw = {}
+    if case == "s1_c128":
+        B, L, Ci, Co, k = 170, 200, 128, 128, 3
+    elif case == "s1_c256":
+        B, L, Ci, Co, k = 1400, 25, 256, 256, 3
+    elif case == "s2":
+        B, L, Ci, Co, k = 1400, 50, 128, 256, 3
+        kw["stride"] = 2
+    elif case == "up":
+        B, L, Ci, Co, k = 1400, 13, 256, 256, 3
+        kw["upmap_to"] = 25
+    elif case == "k1_res":
+        B, L, Ci, Co, k = 2600, 13, 256, 768, 1
+    else:
+        B, L, Ci, Co, k = 331, 101, 64, 384, 3   # N = 33431: ragged last row tile; Co = 384 -> 128-wide channel tiles
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / (k * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    if case == "k1_res":
+        kw.update(res=torch.randn(B, Co, L, generator=g), ebias=torch.randn(B, Co + 8, generator=g), act=2)
+    got = run_conv(dt, x, w, b, **kw)
+    _lib.lib().tdx_conv_gemm_force_small(1)
+    try:
+        small = run_conv(dt, x, w, b, **kw)
+    finally:
+        _lib.lib().tdx_conv_gemm_force_small(0)
+    assert torch.equal(got, small)
+    xq = q(x, dt)
+    if "upmap_to" in kw:
+        xq = F.interpolate(xq, size=kw["upmap_to"], mode="nearest")
+    ref = F.conv1d(xq, q(w, dt), b, stride=kw.get("stride", 1), padding=k // 2)
+    if case == "k1_res":
+        ref = swish(ref + kw["ebias"][:, 8:, None]) + q(kw["res"], dt)
+    assert rel(got, ref) < TOL[dt]
 
 
 def test_conv_rejects_bad_arguments():

@@ -100,10 +100,9 @@ class UNetProgram:
                     pg.release(t)
                 srcs = [(nxt, co)]
             cur = srcs[0][0]
-            upmap = engine.nearest_map(li, lo).to(pg.device)
             uconv = m.up_blocks[i][m.res_blocks]
             nxt = pg.alloc((B, lo, co))
-            pg.conv([engine.Seg(cur, co, co, li, upmap=upmap, lvirt=lo)], packed[f"up_blocks.{i}.up.w"],
+            pg.conv([engine.Seg(cur, co, co, li, lvirt=lo)], packed[f"up_blocks.{i}.up.w"],
                     engine.fp32_param(uconv.bias, f"up_blocks.{i}.{m.res_blocks}.bias"), nxt, co, B, lo, co, name=f"up_blocks.{i}.up")
             pg.release(cur)
             cur = nxt

@@ -20,7 +20,7 @@ _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_
 
 
 class KSeg(C.Structure):
-    _fields_ = [("src", _vp), ("upmap", _vp), ("src_ld", _i32), ("ch_off", _i32), ("cin", _i32), ("taps", _i32),
+    _fields_ = [("src", _vp), ("up_scale", _f32), ("reserved0", _i32), ("src_ld", _i32), ("ch_off", _i32), ("cin", _i32), ("taps", _i32),
                 ("stride", _i32), ("lin", _i32), ("lvirt", _i32), ("reserved", _i32)]
 
 
@@ -36,6 +36,8 @@ _SIGNATURES = {
     "tdx_version": (_i32, []),
     "tdx_device_ok": (_i32, []),
     "tdx_conv_gemm": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "tdx_conv_gemm_force_small": (_i32, [_i32]),
+    "tdx_conv_gemm_debug": (_i32, [_i32]),
     "tdx_groupnorm_act": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "tdx_stem_conv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tdx_head_conv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

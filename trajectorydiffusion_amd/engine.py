@@ -38,12 +38,13 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 class Seg:
     """One K-segment of a gathered GEMM (see tdx_kseg in include/trajdiff_hip.h)."""
-    __slots__ = ("src", "ld", "ch_off", "cin", "taps", "stride", "lin", "lvirt", "upmap")
+    __slots__ = ("src", "ld", "ch_off", "cin", "taps", "stride", "lin", "lvirt")
 
     def __init__(self, src: torch.Tensor, ld: int, cin: int, lin: int, taps: int = 3, stride: int = 1, ch_off: int = 0,
-                 upmap: Optional[torch.Tensor] = None, lvirt: Optional[int] = None):
+                 lvirt: Optional[int] = None):
+        """lvirt != lin: the conv runs on F.interpolate(src, size=lvirt, mode='nearest') without materialising it."""
         self.src, self.ld, self.ch_off, self.cin, self.taps, self.stride = src, ld, ch_off, cin, taps, stride
-        self.lin, self.upmap = lin, upmap
+        self.lin = lin
         self.lvirt = lin if lvirt is None else lvirt
 
 
@@ -88,12 +89,12 @@ class Program:
         ktot = 0
         for i, s in enumerate(segs):
             k = d.seg[i]
-            k.src, k.upmap = s.src.data_ptr(), (s.upmap.data_ptr() if s.upmap is not None else None)
+            k.src = s.src.data_ptr()
+            # ATen's nearest scale: static_cast<float>(input_size) / output_size, one fp32 division
+            k.up_scale = float(torch.tensor(float(s.lin), dtype=torch.float32) / torch.tensor(float(s.lvirt), dtype=torch.float32))
             k.src_ld, k.ch_off, k.cin, k.taps, k.stride, k.lin, k.lvirt = s.ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt
             ktot += s.taps * s.cin
             self.keep.append(s.src)
-            if s.upmap is not None:
-                self.keep.append(s.upmap)
         if tuple(w.shape) != (cout, ktot):
             raise TdxError(f"{name}: packed weight is {tuple(w.shape)}, segments need ({cout}, {ktot})")
         d.nseg, d.dtype = len(segs), self.code if dtype_code is None else dtype_code

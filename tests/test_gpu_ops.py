@@ -135,8 +135,8 @@ def test_conv_concat_plus_shortcut_segments(dt):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("case", ["s1_c128", "s1_c256", "s2", "up", "k1_res", "tail_rows"])
 def test_conv_large_tiles_dma_kernel(dt, case):
-    """Shapes big enough for the 256-row LDS-DMA kernel: checked against F.conv1d AND bit-for-bit against the
-    128x128 register-staged kernel (same K order, same MFMA chain => identical fp32 sums)."""
+    """Shapes big enough for the 256-row LDS-DMA kernels (window and gather variants): checked against F.conv1d AND
+    bit-for-bit against each other and the 128x128 register-staged kernel (same K order, same MFMA chain)."""
     engine, _lib = _eng()
     g = torch.Generator().manual_seed(len(case))
     kw = {}
@@ -160,12 +160,13 @@ def test_conv_large_tiles_dma_kernel(dt, case):
     if case == "k1_res":
         kw.update(res=torch.randn(B, Co, L, generator=g), ebias=torch.randn(B, Co + 8, generator=g), act=2)
     got = run_conv(dt, x, w, b, **kw)
-    _lib.lib().tdx_conv_gemm_force_small(1)
-    try:
-        small = run_conv(dt, x, w, b, **kw)
-    finally:
-        _lib.lib().tdx_conv_gemm_force_small(0)
-    assert torch.equal(got, small)
+    for bits in (1, 2):  # 1: register-staged 128x128 kernel; 2: LDS-DMA kernel without the shared tap window
+        _lib.lib().tdx_conv_gemm_force_small(bits)
+        try:
+            other = run_conv(dt, x, w, b, **kw)
+        finally:
+            _lib.lib().tdx_conv_gemm_force_small(0)
+        assert torch.equal(got, other), bits
     xq = q(x, dt)
     if "upmap_to" in kw:
         xq = F.interpolate(xq, size=kw["upmap_to"], mode="nearest")

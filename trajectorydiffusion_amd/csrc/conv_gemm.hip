@@ -2,7 +2,9 @@
 //
 //   out[n, co] = act(sum_k W[co, k] * X[n, k] + biases) + res[n, co]
 //
-// n runs over the B*lout output rows (channels-last), k over (segment, tap, channel).  The X
+// n runs over the B*lout output rows (channels-last), k over (segment, 128-byte channel block, tap,
+// channel in block): taps are the INNER loop, so the three shifted reads of a conv hit rows that are
+// already in L2/LDS.  The X
 // operand is never materialised: for every (segment, tap) each staged tile row is fetched
 // through its own source-row pointer (conv zero padding, stride 2, nearest-upsampling, the
 // decoder's channel concat and the 1x1 shortcut are all just different pointers), and
@@ -43,10 +45,21 @@ struct ConvArgs {
   int32_t debug;  // ablation bits for scripts/conv_bench.py: 1 = no loads after the first stage, 2 = no MFMA, 4 = no stores
 };
 
-bool g_force_small = false;
-int g_debug = 0;  // test hook: route everything through the 128x128 register-staged kernel
+int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
+int g_debug = 0;
 constexpr int kRowBytes = 128;  // one K-step of one tile row: 64 bf16 / 32 fp32
 constexpr int kThreads = 256;
+
+// Run f(integral_constant<int, tap>) for a wave-uniform runtime tap in {0, 1, 2}: every per-tap register array is then
+// indexed by a compile-time constant (a runtime index, or a select between elements, sends the array to scratch).
+template <int N>
+struct TapC { static constexpr int value = N; };
+template <typename F>
+__device__ __forceinline__ void with_tap(int tap, F&& f) {
+  if (tap == 0) f(TapC<0>{});
+  else if (tap == 1) f(TapC<1>{});
+  else f(TapC<2>{});
+}
 
 template <typename T>
 struct Mma;
@@ -194,7 +207,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   }
 }
 
-// TR x TC output tile (rows x channels); 4 waves as 2 (channels) x 2 (rows); each wave (TC/2) x (TR/2).
+// ------------------------------------------------------------------------------------------------------
+// Small / general kernel: TR x TC tile, 4 waves as 2 (channels) x 2 (rows), operands staged through VGPRs.
+// Handles every legal descriptor (channel counts that are not whole 128-byte blocks, tiny problems).
 template <typename T, int TR, int TC>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
   constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -211,11 +226,11 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
   // an L2.  Give each of those 8 streams its own row tiles and let it walk all channel tiles of a row tile
   // back to back: an activation tile is then fetched into ONE L2 and re-used there by every channel tile.
   const int nco = (p.cout + TC - 1) / TC;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int row_tile = (j / nco) * 8 + xcd;
+  const int xcd = blockIdx.x & 7, jt = blockIdx.x >> 3;
+  const int row_tile = (jt / nco) * 8 + xcd;
   const int n0 = row_tile * TR;
   if (n0 >= p.N) return;  // block-uniform: padding blocks of the last group of 8 row tiles
-  const int co0 = (j % nco) * TC;
+  const int co0 = (jt % nco) * TC;
 
   // ---- staging role: 16-byte chunk c of rows rbase + 32*i -----------------------------------
   const int c = tid & 7, rbase = tid >> 3;
@@ -238,48 +253,53 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
     wrow[i] = co < p.cout ? p.w + ((size_t)co * p.ktot + c * VEC) * sizeof(T) : nullptr;
   }
 
-  // ---- K iterator (segment, tap, channel block) ------------------------------------------------
+  // ---- K iterator (segment, channel block, tap) --------------------------------------------------
   int it_seg = 0, it_tap = 0, it_ci = 0;
-  const char* xrow[RB];
+  const char* xrow[3][RB];  // per-tap source row pointers of the current segment (statically indexed only)
   auto set_rows = [&]() {
     const SegDev& s = p.seg[it_seg];
     const int pad = s.taps == 3 ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      int u = rb_l[i] * s.stride + it_tap - pad;
-      bool ok = rb_ok[i] && u >= 0 && u < s.lvirt;
-      int uu = ok ? u : 0;
-      int srow = s.up_scale > 0.f ? min((int)floorf((float)uu * s.up_scale), s.lin - 1) : uu;
-      xrow[i] = ok ? s.src + ((size_t)(rb_b[i] * s.lin + srow) * s.src_ld + s.ch_off + c * VEC) * sizeof(T) : nullptr;
-    }
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        int u = rb_l[i] * s.stride + t - pad;
+        bool ok = t < s.taps && rb_ok[i] && u >= 0 && u < s.lvirt;
+        int uu = ok ? u : 0;
+        int srow = s.up_scale > 0.f ? min((int)floorf((float)uu * s.up_scale), s.lin - 1) : uu;
+        xrow[t][i] = ok ? s.src + ((size_t)(rb_b[i] * s.lin + srow) * s.src_ld + s.ch_off + c * VEC) * sizeof(T) : nullptr;
+      }
   };
   set_rows();
 
   u32x4 ra[RA], rx[RB];
   auto load_step = [&]() {
     const SegDev& s = p.seg[it_seg];
-    const bool chunk_ok = it_ci + c * VEC < s.cin;
-    const size_t koff = (size_t)(s.k0 + it_tap * s.cin + it_ci) * sizeof(T);
+    const int blen = s.cin - it_ci < BK ? s.cin - it_ci : BK;
+    const bool chunk_ok = c * VEC < blen;
+    const size_t koff = (size_t)(s.k0 + it_ci * s.taps + it_tap * blen) * sizeof(T);
     const size_t xoff = (size_t)it_ci * sizeof(T);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const char* g = (wrow[i] && chunk_ok) ? wrow[i] + koff : zero;
       ra[i] = *reinterpret_cast<const u32x4*>(g);
     }
+    with_tap(it_tap, [&](auto tc) {
+      constexpr int TAP = decltype(tc)::value;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const char* g = (xrow[i] && chunk_ok) ? xrow[i] + xoff : zero;
-      rx[i] = *reinterpret_cast<const u32x4*>(g);
-    }
-    // advance
-    it_ci += BK;
-    if (it_ci >= s.cin) {
-      it_ci = 0;
-      if (++it_tap >= s.taps) {
-        it_tap = 0;
-        ++it_seg;
+      for (int i = 0; i < RB; ++i) {
+        const char* g = (xrow[TAP][i] && chunk_ok) ? xrow[TAP][i] + xoff : zero;
+        rx[i] = *reinterpret_cast<const u32x4*>(g);
       }
-      if (it_seg < p.nseg) set_rows();
+    });
+    if (++it_tap >= s.taps) {
+      it_tap = 0;
+      it_ci += BK;
+      if (it_ci >= s.cin) {
+        it_ci = 0;
+        ++it_seg;
+        if (it_seg < p.nseg) set_rows();
+      }
     }
   };
   auto store_step = [&](int buf) {
@@ -331,7 +351,6 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
     if (more) store_step((s + 1) & 1);
     __syncthreads();
   }
-
   epilogue<T, MI, NI>(p, acc, n0 + wr * (TR / 2), co0 + wc * (TC / 2), fr, fq);
 }
 
@@ -352,16 +371,24 @@ int launch(const ConvArgs& a, hipStream_t st) {
   return TDX_OK;
 }
 
-
 // ------------------------------------------------------------------------------------------------------
 // Large-problem kernel: 256-row x TC-channel tile, 8 waves (2 channel x 4 row), both operands brought in by
 // LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR staging).  The DMA writes LDS lane-linearly, so the
 // bank-conflict XOR swizzle lives in the per-lane SOURCE chunk (lane (r, c) of an 8-row group fetches chunk
 // c ^ r) and in the fragment reads.  Out-of-range rows (conv padding, tile tails) use an out-of-range buffer
-// offset: the DMA then writes zeros.  Two LDS stages, one barrier per K-step, loads of step s+1 in flight
-// under the MFMAs of step s.
+// offset: the DMA then writes zeros.  Weight stages are double-buffered, one barrier per K-step, the DMA of
+// step s+1 in flight under the MFMAs of step s.
+//
+// WIN = false ("gather"): the activation tile of every (channel block, tap) is gathered row by row, which also
+//   covers stride 2 and nearest-upsampled sources.
+// WIN = true  ("window"): stride-1 identity-mapped segments.  One window of 256 + 2 consecutive source rows per
+//   channel block is staged ONCE and serves all three taps: tap t of output row i reads window row i + t, or a
+//   permanently-zero LDS row when l + t - 1 falls outside the trajectory (Conv1d's padding).  Activation
+//   traffic into LDS drops 3x and the window for block j+1 streams in under the three tap steps of block j.
 constexpr int kDmaThreads = 512;
 constexpr int kDmaRows = 256;
+constexpr int kWinGroups = kDmaRows / 8 + 1;             // 8-row DMA groups per window (rows 0..263)
+constexpr int kWinBytes = (kWinGroups * 8 + 1) * kRowBytes;  // + one zero row
 constexpr uint32_t kOob = 0x80000000u;
 
 // Buffer resource words {base_lo, base_hi (stride 0), num_records, flags}, forced into SGPRs.
@@ -378,9 +405,12 @@ __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from srd[voff + soff] to LDS[lds_addr + 16*lane]; out-of-range
 // lanes write zeros.  Issued through asm on purpose: hipcc orders every later ds_read behind a DMA it can see
 // (s_waitcnt vmcnt(0) before the first fragment read), which would serialise the loads of step s+1 with the MFMAs
-// of step s.  The kernel waits for its DMAs itself (vmcnt(0) + barrier at the top of each K-step).
+// of step s.  The kernel waits for its DMAs itself (vmcnt(0) + barrier at the top of each K-step), and its main
+// loop contains no compiler-visible vector-memory load, so hipcc inserts no vmcnt wait of its own there.
 __device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const u32x4& srd, uint32_t soff) {
   uint32_t keep;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);  // wave-uniform by construction; make it provably an SGPR
+  soff = __builtin_amdgcn_readfirstlane(soff);
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %1\n\t"
@@ -392,14 +422,18 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const u3
       : "memory");
 }
 
-template <typename T, int TC>
+template <typename T, int TC, bool WIN>
 __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   constexpr int TR = kDmaRows;
   constexpr int ES = (int)sizeof(T);
+  constexpr int BK = kRowBytes / ES;
   constexpr int MI = TC / 32, NI = TR / 64;       // wave tile: (TC/2) channels x 64 rows
   constexpr int GA = TC / 64, GB = TR / 64;       // 8-row DMA groups per wave per stage
-  constexpr int A_BYTES = TC * kRowBytes, B_BYTES = TR * kRowBytes, STAGE = A_BYTES + B_BYTES;
+  constexpr int GW = (kWinGroups + 7) / 8;        // window groups per wave (last one partial)
+  constexpr int A_BYTES = TC * kRowBytes, B_BYTES = TR * kRowBytes;
+  constexpr int A_STAGE = WIN ? A_BYTES : A_BYTES + B_BYTES;  // distance between the two weight stages
+  constexpr int W_BASE = 2 * A_BYTES;                          // WIN: the two activation windows follow the weight stages
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -413,8 +447,9 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
   const int n0 = row_tile * TR;
   if (n0 >= p.N) return;
   const int co0 = (jt % nco) * TC;
+  const int fr = lane & 15, fq = lane >> 4;
 
-  // ---- loader role -----------------------------------------------------------------------------------
+  // ---- weight (A) loader: linear walk over the packed K axis ---------------------------------------------
   const int r8 = lane >> 3;
   const uint32_t chunk_off = (uint32_t)(((lane & 7) ^ r8) << 4);
   const int rows_a = p.cout - co0 < TC ? p.cout - co0 : TC;
@@ -422,64 +457,106 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
   uint32_t voff_a[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) voff_a[i] = (uint32_t)(8 * (wave + 8 * i) + r8) * (uint32_t)(p.ktot * ES) + chunk_off;  // rows >= rows_a fall out of range
-
-  const int b0 = n0 / p.lout;
-  int rb_b[GB], rb_l[GB];
-#pragma unroll
-  for (int i = 0; i < GB; ++i) {
-    const int n = n0 + 8 * (wave + 8 * i) + r8;
-    const int b = n / p.lout;
-    rb_b[i] = n < p.N ? b - b0 : -1;
-    rb_l[i] = n - b * p.lout;
-  }
-  int it_seg = 0, it_tap = 0, it_ci = 0;
   uint32_t soff_a = 0;
-  uint32_t voff_b[GB];
-  u32x4 rsrc_b;
-  auto set_rows = [&]() {
-    const SegDev& s = p.seg[it_seg];
-    const size_t base = ((size_t)b0 * s.lin * s.src_ld + s.ch_off) * ES;
-    const size_t total = (size_t)p.B * s.lin * s.src_ld * ES;
-    const size_t left = total - base;
-    rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
-    const int pad = s.taps == 3 ? 1 : 0;
+  auto issue_a = [&](int buf) {
+    const uint32_t a = lds_base + buf * A_STAGE + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
 #pragma unroll
-    for (int i = 0; i < GB; ++i) {
-      const int u = rb_l[i] * s.stride + it_tap - pad;
-      const bool ok = rb_b[i] >= 0 && u >= 0 && u < s.lvirt;
-      const int uu = ok ? u : 0;
-      const int srow = s.up_scale > 0.f ? min((int)floorf((float)uu * s.up_scale), s.lin - 1) : uu;
-      voff_b[i] = ok ? (uint32_t)((rb_b[i] * s.lin + srow) * s.src_ld) * ES + chunk_off : kOob;
+    for (int i = 0; i < GA; ++i) dma16(a + i * 8192, voff_a[i], rsrc_a, so);
+    soff_a += kRowBytes;
+  };
+
+  // ---- activation (B) loader -------------------------------------------------------------------------------
+  u32x4 rsrc_b;
+  int ld_seg = 0, ld_ci = 0, ld_tap = 0;   // loader iterator (gather: per step; window: per channel block)
+  int ld_taps = 1, ld_cin = 0;             // cached fields of segment ld_seg (no kernarg loads inside the K loop)
+  // gather state
+  uint32_t voff_b[3][WIN ? 1 : GB];
+  int rb_b[WIN ? 1 : GB], rb_l[WIN ? 1 : GB];
+  // window state
+  uint32_t voff_w[WIN ? GW : 1];
+
+  auto ld_setup = [&]() {  // per segment
+    const SegDev& s = p.seg[ld_seg];
+    ld_taps = s.taps;
+    ld_cin = s.cin;
+    if constexpr (WIN) {
+      const int pad = s.taps == 3 ? 1 : 0;
+      const int base_row = n0 - pad > 0 ? n0 - pad : 0;
+      const size_t base = ((size_t)base_row * s.src_ld + s.ch_off) * ES;
+      const size_t left = (size_t)p.N * s.src_ld * ES - base;
+      rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
+#pragma unroll
+      for (int i = 0; i < GW; ++i) {
+        const int srow = n0 - pad + 8 * (wave + 8 * i) + r8;  // flat source row of this lane's window row
+        voff_w[i] = (srow >= 0 && srow < p.N) ? (uint32_t)((srow - base_row) * s.src_ld) * ES + chunk_off : kOob;
+      }
+    } else {
+      const int b0 = n0 / p.lout;
+      const size_t base = ((size_t)b0 * s.lin * s.src_ld + s.ch_off) * ES;
+      const size_t left = (size_t)p.B * s.lin * s.src_ld * ES - base;
+      rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
+      const int pad = s.taps == 3 ? 1 : 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const int u = rb_l[i] * s.stride + t - pad;
+          const bool ok = t < s.taps && rb_b[i] >= 0 && u >= 0 && u < s.lvirt;
+          const int uu = ok ? u : 0;
+          const int srow = s.up_scale > 0.f ? min((int)floorf((float)uu * s.up_scale), s.lin - 1) : uu;
+          voff_b[t][i] = ok ? (uint32_t)((rb_b[i] * s.lin + srow) * s.src_ld) * ES + chunk_off : kOob;
+        }
     }
   };
-  set_rows();
+  if constexpr (!WIN) {
+    const int b0 = n0 / p.lout;
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int n = n0 + 8 * (wave + 8 * i) + r8;
+      const int b = n / p.lout;
+      rb_b[i] = n < p.N ? b - b0 : -1;
+      rb_l[i] = n - b * p.lout;
+    }
+  }
+  ld_setup();
 
-  auto issue = [&](int buf) {
-    const uint32_t a = lds_base + buf * STAGE + wave * 1024;
-    const uint32_t b = a + A_BYTES;
-    const uint32_t soff_b = __builtin_amdgcn_readfirstlane((uint32_t)it_ci * ES);
-    const uint32_t soff_a_u = __builtin_amdgcn_readfirstlane(soff_a);
+  // gather: one activation tile per K-step, next to its weight stage
+  auto issue_b_gather = [&](int buf) {
+    const uint32_t b = lds_base + buf * A_STAGE + A_BYTES + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
+    with_tap(ld_tap, [&](auto tc) {
+      constexpr int TAP = decltype(tc)::value;
 #pragma unroll
-    for (int i = 0; i < GA; ++i) dma16(a + i * 8192, voff_a[i], rsrc_a, soff_a_u);
-#pragma unroll
-    for (int i = 0; i < GB; ++i) dma16(b + i * 8192, voff_b[i], rsrc_b, soff_b);
-    soff_a += kRowBytes;
-    it_ci += kRowBytes / ES;
-    const SegDev& s = p.seg[it_seg];
-    if (it_ci >= s.cin) {
-      it_ci = 0;
-      if (++it_tap >= s.taps) {
-        it_tap = 0;
-        ++it_seg;
+      for (int i = 0; i < (WIN ? 0 : GB); ++i) dma16(b + i * 8192, voff_b[TAP][i], rsrc_b, so);
+    });
+    if (++ld_tap >= ld_taps) {
+      ld_tap = 0;
+      ld_ci += BK;
+      if (ld_ci >= ld_cin) {
+        ld_ci = 0;
+        ++ld_seg;
+        if (ld_seg < p.nseg) ld_setup();
       }
-      if (it_seg < p.nseg) set_rows();
+    }
+  };
+  // window: one window per channel block
+  auto issue_window = [&](int wbuf) {
+    const uint32_t w = lds_base + W_BASE + wbuf * kWinBytes + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
+#pragma unroll
+    for (int i = 0; i < (WIN ? GW : 0); ++i)
+      if (wave + 8 * i < kWinGroups) dma16(w + i * 8192, voff_w[i], rsrc_b, so);
+    ld_ci += BK;
+    if (ld_ci >= ld_cin) {
+      ld_ci = 0;
+      ++ld_seg;
+      if (ld_seg < p.nseg) ld_setup();
     }
   };
 
   // ---- MFMA role ---------------------------------------------------------------------------------------
-  const int fr = lane & 15, fq = lane >> 4;
   const int a_frag = (wc * (TC / 2) + fr) * kRowBytes;
-  const int b_frag = (wr * 64 + fr) * kRowBytes;
   const int sw = fr & 7;
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -487,15 +564,55 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf) {
-    const char* a = smem + buf * STAGE;
-    const char* b = a + A_BYTES;
+  // window mode: tap t of output row i reads window row i + t; padding taps (l + t - 1 outside the trajectory) and
+  // rows past the end of the problem read the zero row instead.  One validity bit per (sub-tile, tap).
+  int cp_seg = 0, cp_ci = 0, cp_tap = 0, cp_blk = 0;  // compute iterator (window mode)
+  int cp_taps = 1, cp_cin = 0;
+  uint32_t wmask = 0;
+  int wl[WIN ? NI : 1];
+  auto cp_setup = [&]() {
+    const SegDev& s = p.seg[cp_seg];
+    cp_taps = s.taps;
+    cp_cin = s.cin;
+    wmask = 0;
+#pragma unroll
+    for (int ni = 0; ni < (WIN ? NI : 0); ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int u = s.taps == 3 ? wl[ni] + t - 1 : wl[ni];
+        const bool ok = t < s.taps && wl[ni] >= 0 && u >= 0 && u < p.lout;
+        wmask |= (ok ? 1u : 0u) << (ni * 3 + t);
+      }
+  };
+  if constexpr (WIN) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wr * 64 + ni * 16 + fr;
+      wl[ni] = n < p.N ? n % p.lout : -1;
+    }
+    cp_setup();
+    if (tid < 16)  // the two zero rows (never touched by the DMA)
+      *reinterpret_cast<u32x4*>(smem + W_BASE + (tid >> 3) * kWinBytes + kWinGroups * 8 * kRowBytes + (tid & 7) * 16) =
+          (u32x4){0u, 0u, 0u, 0u};
+  }
+
+  auto compute = [&](int abuf, int wbuf) {
+    const char* a = smem + abuf * A_STAGE;
+    const char* b = WIN ? smem + W_BASE + wbuf * kWinBytes : a + A_BYTES;
+    int boff[NI];
+    const int shift = WIN ? (cp_taps == 3 ? cp_tap : 0) : 0;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int wrow = wr * 64 + ni * 16 + fr + shift;
+      boff[ni] = wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4);
+      if constexpr (WIN) boff[ni] = ((wmask >> (ni * 3 + cp_tap)) & 1u) ? boff[ni] : kWinGroups * 8 * kRowBytes;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = (((kk << 2) + fq) ^ sw) << 4;
       u32x4 af[MI], bf[NI];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(b + b_frag + ni * 16 * kRowBytes + ch);
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(b + (boff[ni] ^ (kk << 6)));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(a + a_frag + mi * 16 * kRowBytes + ch);
 #pragma unroll
@@ -505,12 +622,34 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     }
   };
 
-  issue(0);
+  // ---- main loop ---------------------------------------------------------------------------------------------
+  const bool no_load = p.debug & 1, no_mma = p.debug & 2;
+  if constexpr (WIN) issue_window(0);
+  issue_a(0);
+  if constexpr (!WIN) issue_b_gather(0);
   for (int s = 0; s < p.nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for step s has landed ...
-    __syncthreads();                                    // ... and so has everyone's; all waves are done reading stage (s+1)&1
-    if (s + 1 < p.nsteps && !(p.debug & 1)) issue((s + 1) & 1);
-    if (!(p.debug & 2)) compute(s & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs for step s have landed ...
+    __syncthreads();                                    // ... and so have everyone's; all waves are done reading the buffers refilled below
+    if (s + 1 < p.nsteps && !no_load) {
+      issue_a((s + 1) & 1);
+      if constexpr (!WIN) issue_b_gather((s + 1) & 1);
+    }
+    if constexpr (WIN) {
+      if (cp_tap == 0 && ld_seg < p.nseg && !no_load) issue_window((cp_blk + 1) & 1);  // window of the NEXT channel block
+    }
+    if (!no_mma) compute(s & 1, cp_blk & 1);
+    if constexpr (WIN) {
+      if (++cp_tap >= cp_taps) {
+        cp_tap = 0;
+        ++cp_blk;
+        cp_ci += BK;
+        if (cp_ci >= cp_cin) {
+          cp_ci = 0;
+          ++cp_seg;
+          if (cp_seg < p.nseg) cp_setup();
+        }
+      }
+    }
   }
   if (p.debug & 4) {
     float t = 0.f;
@@ -527,21 +666,27 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
 #endif
 }
 
-template <typename T, int TC>
+template <typename T, int TC, bool WIN>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
   const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + kDmaRows - 1) / kDmaRows;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
-  size_t lds = 2 * (size_t)(kDmaRows + TC) * kRowBytes;
+  size_t lds = WIN ? 2 * (size_t)TC * kRowBytes + 2 * (size_t)kWinBytes : 2 * (size_t)(kDmaRows + TC) * kRowBytes;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_dma: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC>), grid, dim3(kDmaThreads), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC, WIN>), grid, dim3(kDmaThreads), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_dma_kernel");
   return TDX_OK;
+}
+
+template <typename T>
+int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, bool win) {
+  if (win) return tc == 256 ? launch_dma<T, 256, true>(a, st) : launch_dma<T, 128, true>(a, st);
+  return tc == 256 ? launch_dma<T, 256, false>(a, st) : launch_dma<T, 128, false>(a, st);
 }
 
 }  // namespace
@@ -600,27 +745,30 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   a.B = d->B;
   a.debug = g_debug;
   hipStream_t st = (hipStream_t)stream;
-  // LDS-DMA kernel: whole K-steps only, 32-bit in-tile offsets, and enough 256-row tiles to fill the chip
-  bool dma_ok = !g_force_small;
+  // LDS-DMA kernels: whole 128-byte channel blocks only, 32-bit in-tile offsets, 16-byte epilogue vectors, and
+  // enough 256-row tiles to fill the chip.  Window variant: every segment stride 1 on an un-resampled source.
+  bool dma_ok = !(g_force & 1), win_ok = !(g_force & 2);
   for (int i = 0; i < d->nseg; ++i) {
     const tdx_kseg& s = d->seg[i];
     dma_ok = dma_ok && s.cin % bk == 0 && ((int64_t)(kDmaRows / d->lout + 2) * s.lin * s.src_ld * es < (1ll << 31));
+    win_ok = win_ok && s.stride == 1 && s.lvirt == s.lin && s.lin == d->lout && ((int64_t)(kDmaRows + 16) * s.src_ld * es < (1ll << 31));
   }
   dma_ok = dma_ok && (int64_t)kDmaRows * k * es < (1ll << 31);
   dma_ok = dma_ok && d->cout % vec == 0 && d->out_off % vec == 0 && d->out_ld % vec == 0 && (!d->res || d->res_ld % vec == 0);
   const int tc = (d->cout % 256 == 0) ? 256 : 128;
   const int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
   if (dma_ok && tiles >= 128) {
-    if (d->dtype == TDX_F32) return tc == 256 ? launch_dma<float, 256>(a, st) : launch_dma<float, 128>(a, st);
-    return tc == 256 ? launch_dma<__bf16, 256>(a, st) : launch_dma<__bf16, 128>(a, st);
+    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, tc, win_ok);
+    return dispatch_dma<__bf16>(a, st, tc, win_ok);
   }
   if (d->dtype == TDX_F32) return launch<float, 128, 128>(a, st);
   return launch<__bf16, 128, 128>(a, st);
 }
 
-// Test hook (not part of the reference-facing surface): force the small-tile kernel so both kernels can be compared.
-extern "C" int tdx_conv_gemm_force_small(int32_t on) {
-  g_force_small = on != 0;
+// Test hooks (not part of the reference-facing surface).
+// force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant.
+extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
+  g_force = bits;
   return TDX_OK;
 }
 extern "C" int tdx_conv_gemm_debug(int32_t bits) {

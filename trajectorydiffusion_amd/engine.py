@@ -32,8 +32,18 @@ def nearest_map(l_in: int, l_out: int) -> torch.Tensor:
 
 
 def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """(Cout, Cin, k) -> (Cout, k*Cin) with K order (tap, channel), cast to the compute dtype."""
-    return w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+    """(Cout, Cin, k) -> (Cout, k*Cin) in the kernels' K order, cast to the compute dtype.
+
+    K order = (128-byte channel block, tap, channel in block): the taps of one channel block are adjacent, so the
+    three shifted reads of a k=3 conv happen back to back on rows that are already on chip.
+    """
+    w = w.detach()
+    cout, cin, k = w.shape
+    bk = 128 // torch.empty((), dtype=dtype).element_size()
+    if k == 1:
+        return w.reshape(cout, cin).to(dtype).contiguous()
+    blocks = [w[:, c0:c0 + bk, :].permute(0, 2, 1).reshape(cout, -1) for c0 in range(0, cin, bk)]
+    return torch.cat(blocks, dim=1).to(dtype).contiguous()
 
 
 class Seg:

@@ -1,0 +1,117 @@
+"""CPU: host-side logic, the C-ABI surface (symbols only, no compute) and the multi-process shard/gather path."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from trajectorydiffusion_amd import _lib
+    header = open(os.path.join(ROOT, "include", "trajdiff_hip.h")).read()
+    declared = set(re.findall(r"\b(tdx_[a-z0-9_]+)\s*\(", header))
+    assert {"tdx_conv_gemm", "tdx_groupnorm_act", "tdx_ddpm_update", "tdx_attention", "tdx_didi_items"} <= declared
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/trajdiff_hip.h but not exported"
+    assert declared <= set(_lib.EXPORTS) | {"tdx_last_error"}
+    assert handle.tdx_version() >= 100 and isinstance(handle.tdx_last_error(), bytes)
+
+
+def test_state_dict_keys_match_reference_and_default_init_is_deterministic(golden_dir):
+    import json
+    from trajectorydiffusion_amd import TrajUNet
+    spec = json.load(open(os.path.join(golden_dir, "state_dict_spec.json")))
+    torch.manual_seed(0)
+    m = TrajUNet([128, 128, 256, 512, 1024], diffusion_steps=500, res_blocks=2)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, s) for k, s in spec]
+    assert len(list(m.buffers())) == 0 and not isinstance(m.embed_block.pos_enc, torch.nn.Parameter)
+    assert sum(p.numel() for p in m.parameters()) == 50_039_170
+    assert m.embed_cols == 6912 and len(dict(m.executed_resblocks())) == 14
+    with pytest.raises(Exception):
+        TrajUNet([128, 128], res_blocks=1)
+
+
+def test_no_cpu_fallback():
+    from trajectorydiffusion_amd import DiffusionManager, TrajUNet
+    from trajectorydiffusion_amd._lib import TdxError
+    m = TrajUNet([32, 32, 64], diffusion_steps=10).eval()
+    with pytest.raises(TdxError):
+        m(torch.zeros(1, 2, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, 5, dtype=torch.long), torch.zeros(1, 3))
+    dm = DiffusionManager(1e-4, 0.05, 10, device="cpu")
+    with pytest.raises(TdxError):
+        dm.diffusionForward(torch.zeros(1, 2, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, 2, 16))
+
+
+def test_schedule_matches_golden_bit_exact(golden_dir):
+    from trajectorydiffusion_amd import DiffusionManager
+    g = np.load(os.path.join(golden_dir, "schedules.npz"))
+    for tag, args in {"T500": (1e-4, 0.05, 500, False), "default": (1e-4, 0.002, 100, False), "scaled": (1e-4, 0.02, 300, True)}.items():
+        dm = DiffusionManager(args[0], args[1], args[2], device="cpu", scaled_linear=args[3])
+        for k in ("betas", "alphas", "alpha_bars", "sqrt_alpha_bars", "sqrt_1_minus_alphas_bars"):
+            v = getattr(dm, k)
+            assert tuple(v.shape) == (args[2], 1, 1)
+            np.testing.assert_array_equal(v.reshape(-1).numpy(), g[f"{tag}/{k}"])
+
+
+def test_weight_packing_order_and_nearest_map():
+    from oracle import nearest_index_map
+    from trajectorydiffusion_amd import engine
+    w = torch.arange(4 * 96 * 3, dtype=torch.float32).reshape(4, 96, 3)
+    p = engine.pack_conv_weight(w, torch.bfloat16).float()  # 64-channel blocks: [blk0: tap0 c0..63, tap1, tap2][blk1: 32 ch ...]
+    assert p.shape == (4, 288)
+    assert torch.equal(p[:, 0:64], w[:, 0:64, 0].bfloat16().float()) and torch.equal(p[:, 64:128], w[:, 0:64, 1].bfloat16().float())
+    assert torch.equal(p[:, 192:224], w[:, 64:96, 0].bfloat16().float()) and torch.equal(p[:, 256:288], w[:, 64:96, 2].bfloat16().float())
+    p32 = engine.pack_conv_weight(w, torch.float32)           # 32-channel blocks in fp32
+    assert torch.equal(p32[:, 32:64], w[:, 0:32, 1]) and torch.equal(p32[:, 96:128], w[:, 32:64, 0])
+    assert torch.equal(engine.pack_conv_weight(w[:, :, :1], torch.float32), w[:, :, 0])
+    for li, lo in [(13, 25), (25, 50), (100, 200), (24, 47)]:
+        assert torch.equal(engine.nearest_map(li, lo).long(), nearest_index_map(li, lo))
+    assert [engine.conv_out_len(l, 2) for l in (200, 100, 50, 25, 13)] == [100, 50, 25, 13, 7]
+
+
+def test_shard_bounds_cover_batch_exactly():
+    from trajectorydiffusion_amd.distributed import shard_bounds
+    for total in (0, 1, 7, 4096, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from _synth import synth_inputs, synth_noise
+from oracle import DiffusionOracle
+from trajectorydiffusion_amd.distributed import shard_bounds, gather_samples
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B, L, T = 7, 40, 6
+x_T, _, cat, num = synth_inputs(B, L, 500, seed=11)
+o = DiffusionOracle(1e-4, 0.05, T)
+toy = lambda x, t: 0.1 * x + 0.01 * t.view(-1, 1, 1).float()
+full_noise = lambda t: synth_noise(t, (B, 2, L), seed=11)
+ref = o.sample(x_T, toy, full_noise)
+lo, hi = shard_bounds(B, rank, world)
+mine = o.sample(x_T[lo:hi], toy, lambda t: full_noise(t)[lo:hi])   # noise keyed by GLOBAL sample index
+got = gather_samples(mine, B)
+assert got.shape == ref.shape and torch.equal(got, ref), (rank, (got - ref).abs().max())
+dist.barrier(); dist.destroy_process_group(); print("rank", rank, "ok")
+'''
+
+
+def test_two_process_shard_and_gather_equals_unsharded(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2

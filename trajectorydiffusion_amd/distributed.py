@@ -1,0 +1,43 @@
+"""Batch sharding for multi-GPU sampling: one process per GPU, no data-path collective, one final gather.
+
+Trajectories are independent given the weights (reference DiffusionManager.py:57-79), so rank r of n samples
+the contiguous slice shard_bounds(B, r, n) and passes first_sample=lo so that in-kernel Philox noise is keyed
+by the GLOBAL sample index: the gathered result equals the unsharded run bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of `rank`'s contiguous slice; sizes differ by at most one, earlier ranks take the remainder."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_samples(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """all_gather of per-rank sample slices (possibly ragged by one row) into the (total, ...) tensor on every rank."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_bounds(total, r, world) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def sample_sharded(dm, model, x_T: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor, **kw) -> torch.Tensor:
+    """diffusionBackward over this rank's slice of a replicated global batch, then gather."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(x_T.shape[0], rank, world)
+    x0 = dm.diffusionBackward(x_T[lo:hi], cat_attr[lo:hi], num_attr[lo:hi], model, first_sample=lo, **kw)
+    return gather_samples(x0, x_T.shape[0])

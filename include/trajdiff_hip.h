@@ -77,10 +77,25 @@ typedef struct {
   void* out;            /* (B*lout, out_ld) */
   int32_t out_ld;
   int32_t out_off;      /* first output channel written (concat writes) */
-  int32_t B, lout, cout;/* cout multiple of 128 */
+  int32_t B, lout, cout;
   int32_t reserved;
+  /* Optional fused GroupNorm(+act) of the CONSUMER, applied to the finished rows r = out[n, :] (fp32, before
+   * rounding):  gn_out[n, gn_off + co] = gn_act((r - mean[b, g]) * rsqrt(var[b, g] + gn_eps) * gn_gamma[co] + gn_beta[co])
+   * with groups of gn_cpg consecutive output channels over the trajectory's lout rows (biased variance, exact
+   * two-pass, bitwise reproducible).  `out` may be NULL when only the normalised tensor is wanted.
+   * Replaces the nn.GroupNorm + Swish that FOLLOWS a conv (Models/TrajUNetBlocks.py:75-76, :83-84, :109;
+   * Models/TrajUNet.py:43).  Only some shapes can be fused: ask tdx_conv_gemm_gn_fusable() first. */
+  const float* gn_gamma; /* NULL = no fused GroupNorm */
+  const float* gn_beta;
+  void* gn_out;
+  int32_t gn_ld, gn_off, gn_act, gn_cpg;
+  float gn_eps;
+  int32_t reserved2;
 } tdx_conv_desc;
 int tdx_conv_gemm(const tdx_conv_desc* host_desc, void* stream);
+/* 1 if tdx_conv_gemm can run this descriptor WITH its fused GroupNorm, 0 if the caller must run
+ * tdx_groupnorm_act separately (trajectories longer than a 256-row tile, odd channel counts, ...). */
+int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* host_desc);
 
 /* GroupNorm(groups, C, eps, affine) [+ Swish] over channels-last rows, one pass to memory:
  *   out[b, l, out_off + c] = act((x[b,l,c] - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c])

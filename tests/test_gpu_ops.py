@@ -176,6 +176,72 @@ def test_conv_large_tiles_dma_kernel(dt, case):
     assert rel(got, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,L,Ci,Co,cpg,act,raw", [(40, 13, 128, 1024, 32, 2, True), (9, 200, 128, 128, 4, 2, False), (300, 25, 64, 256, 8, 0, True),
+                                                  (7, 100, 256, 256, 16, 2, False), (3, 256, 64, 128, 4, 2, True), (21, 50, 128, 512, 64, 2, True)])
+def test_conv_with_fused_consumer_groupnorm(dt, B, L, Ci, Co, cpg, act, raw):
+    """conv -> (+bias, +embed bias, +residual) -> raw store AND GroupNorm(+Swish) of the consumer in the same launch."""
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(L * 7 + Co)
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, 3, generator=g) / (3 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    eb = torch.randn(B, Co, generator=g)
+    res = torch.randn(B, Co, L, generator=g)
+    gamma, beta = torch.randn(2 * Co, generator=g), torch.randn(2 * Co, generator=g)
+    pre = F.conv1d(q(x, dt), q(w, dt), b, padding=1) + eb[:, :, None] + q(res, dt)
+    ref = F.group_norm(pre, Co // cpg, gamma[Co:], beta[Co:], eps=1e-6)
+    ref = swish(ref) if act == 2 else ref
+
+    class Holder:  # stands in for an nn.GroupNorm: parameters + eps
+        weight, bias, eps = gamma.cuda(), beta.cuda(), 1e-6
+
+    def run():
+        pg = engine.Program(torch.device("cuda"), dt)
+        out = torch.full((B, L, Co), float("nan"), device="cuda", dtype=dt) if raw else None
+        y = torch.zeros((B, L, Co + 16), device="cuda", dtype=dt)
+        spec = engine.GnSpec(Holder, "t", Co, cpg, act, y, Co + 16, 16)
+        pg.conv([engine.Seg(rows(x, dt), Ci, Ci, L)], engine.pack_conv_weight(w.cuda(), dt), b.cuda(), out, Co, B, L, Co,
+                res=rows(res, dt), res_ld=Co, ebias=eb.cuda(), ebias_ld=Co, gn=spec)
+        pg.run()
+        torch.cuda.synchronize()
+        return pg, out, y
+    pg, out, y = run()
+    assert [n for n, _, _ in pg.ops] == ["conv"], "expected the GroupNorm to be fused into the conv launch"
+    got = unrows(y)
+    assert float(got[:, :16].abs().max()) == 0.0
+    tol = 5e-5 if dt == torch.float32 else 1.5e-2
+    assert rel(got[:, 16:], ref) < tol
+    if raw:
+        assert rel(unrows(out), pre) < TOL[dt]
+    _, _, y2 = run()
+    assert torch.equal(y, y2)  # no atomics: bitwise reproducible
+    _lib.lib().tdx_conv_gemm_force_small(4)  # unfused fallback: conv + tdx_groupnorm_act
+    try:
+        pg3, _, y3 = run()
+    finally:
+        _lib.lib().tdx_conv_gemm_force_small(0)
+    assert [n for n, _, _ in pg3.ops] == ["conv", "conv.gn"]
+    assert rel(unrows(y3)[:, 16:], ref) < tol
+
+
+def test_conv_fused_groupnorm_falls_back_when_trajectory_exceeds_tile():
+    engine, _lib = _eng()
+    B, L, C = 2, 300, 128
+    x = torch.randn(B, C, L)
+    w = torch.randn(C, C, 3) / 20
+
+    class Holder:
+        weight, bias, eps = torch.ones(C).cuda(), torch.zeros(C).cuda(), 1e-6
+    pg = engine.Program(torch.device("cuda"), torch.float32)
+    y = torch.zeros((B, L, C), device="cuda")
+    pg.conv([engine.Seg(rows(x, torch.float32), C, C, L)], engine.pack_conv_weight(w.cuda(), torch.float32), None, None, C, B, L, C,
+            gn=engine.GnSpec(Holder, "t", 0, 4, 0, y, C, 0))
+    pg.run()
+    assert len(pg.ops) == 2
+    assert rel(unrows(y), F.group_norm(F.conv1d(x, w, padding=1), 32, eps=1e-6)) < 5e-5
+
+
 def test_conv_rejects_bad_arguments():
     engine, _lib = _eng()
     pg = engine.Program(torch.device("cuda"), torch.float32)

@@ -52,8 +52,11 @@ class UNetProgram:
         self._emit_unet(model, packed)
 
     def _emit_unet(self, m: "TrajUNet", packed: Dict[str, torch.Tensor]) -> None:
+        """Dataflow: every conv GEMM's epilogue also applies the GroupNorm(+Swish) of its consumer, so a ResnetBlock is
+        two launches and the only stand-alone GroupNorm kernels left are the one after the stem and the skip halves of
+        the decoder concats."""
         pg, B, L = self.pg, self.B, self.L
-        cs, NE = m.channel_schedule, m.embed_cols
+        cs, NE, R = m.channel_schedule, m.embed_cols, m.res_blocks
         eb, tb = self.ebias, self.tbias
         lens = [L]
         for _ in range(m.stages):
@@ -62,56 +65,83 @@ class UNetProgram:
         cur = pg.alloc((B, L, cs[0]))
         pg.call("stem", pg.lib.tdx_stem_conv, self.x.data_ptr(), engine.fp32_param(m.stem.weight, "stem.weight").data_ptr(),
                 engine.fp32_param(m.stem.bias, "stem.bias").data_ptr(), cur.data_ptr(), B, L, cs[0], pg.code, keep=[cur])
+        gn_in = engine.block_input_gn(pg, m.down_blocks[0][0], "down_blocks.0.0.", B, L)
+        engine.emit_groupnorm(pg, cur, cs[0], B, L, gn_in, "down_blocks.0.0.gn1")
         downs: List[torch.Tensor] = []
         cur_is_skip = False  # skip tensors stay live until the decoder has consumed them
         for i in range(m.stages):  # encoder, :65-78
             li, co = lens[i], cs[i + 1]
-            for j in range(m.res_blocks):
+            for j in range(R):
                 key = f"down_blocks.{i}.{j}."
                 blk = m.down_blocks[i][j]
-                nxt = engine.emit_resblock(pg, blk, packed, key, [(cur, blk.in_c)], B, li, eb, tb, NE, m.embed_offsets[key])
+                nxt_gn = engine.block_input_gn(pg, m.down_blocks[i][j + 1], f"down_blocks.{i}.{j + 1}.", B, li) if j + 1 < R else None
+                nxt = engine.emit_resblock(pg, blk, packed, key, gn_in.out, [(cur, blk.in_c)], B, li, eb, tb, NE, m.embed_offsets[key],
+                                           next_gn=nxt_gn)
+                pg.release(gn_in.out)
                 if not cur_is_skip:
                     pg.release(cur)
-                cur, cur_is_skip = nxt, False
-            dconv = m.down_blocks[i][m.res_blocks]
+                cur, cur_is_skip, gn_in = nxt, False, nxt_gn
+            dconv = m.down_blocks[i][R]
             d = pg.alloc((B, lens[i + 1], co))
+            if i + 1 < m.stages:
+                gn_in = engine.block_input_gn(pg, m.down_blocks[i + 1][0], f"down_blocks.{i + 1}.0.", B, lens[i + 1])
+            else:
+                gn_in = engine.block_input_gn(pg, m.mid_attn_block.res1, "mid_attn_block.res1.", B, lens[i + 1])
             pg.conv([engine.Seg(cur, co, co, li, stride=2)], packed[f"down_blocks.{i}.down.w"],
-                    engine.fp32_param(dconv.bias, f"down_blocks.{i}.{m.res_blocks}.bias"), d, co, B, lens[i + 1], co,
-                    name=f"down_blocks.{i}.down")
+                    engine.fp32_param(dconv.bias, f"down_blocks.{i}.{R}.bias"), d, co, B, lens[i + 1], co,
+                    name=f"down_blocks.{i}.down", gn=gn_in)
             pg.release(cur)
             downs.append(d)
             cur, cur_is_skip = d, True
         lm = lens[-1]
+
+        def decoder_input_gn(i: int, part_off: int, a1=None):
+            blk = m.up_blocks[i][0]
+            return engine.block_input_gn(pg, blk, f"up_blocks.{i}.0.", B, lens[m.stages - i], part_off, a1)
+
         key = "mid_attn_block."
-        cur = m.mid_attn_block.emit(pg, packed, key, downs[-1], B, lm, eb, tb, NE,
-                                    (m.embed_offsets[key + "res1."], m.embed_offsets[key + "res2."]))
+        gn_up = decoder_input_gn(0, 0)  # first half of the decoder concat = the mid block's output
+        cur = m.mid_attn_block.emit(pg, packed, key, downs[-1], gn_in.out, B, lm, eb, tb, NE,
+                                    (m.embed_offsets[key + "res1."], m.embed_offsets[key + "res2."]), next_gn=gn_up)
+        pg.release(gn_in.out)
         for i in range(m.stages):  # decoder, :81-95
             skip = downs[-i - 1]
             li = lens[m.stages - i]
             lo = lens[m.stages - i - 1]
             cskip = cs[m.stages - i]
             co = cs[m.stages - i - 1]
+            # second half of the concat: GroupNorm+Swish of the skip tensor, written next to the first half
+            engine.emit_groupnorm(pg, skip, cskip, B, li, decoder_input_gn(i, cskip, gn_up.out), f"up_blocks.{i}.0.gn1.skip")
             srcs: List[Tuple[torch.Tensor, int]] = [(cur, cskip), (skip, cskip)]
-            for j in range(m.res_blocks - 1):  # up_stage[:-2]: the last ResnetBlock of each stage is never executed
+            a1 = gn_up.out
+            for j in range(R - 1):  # up_stage[:-2]: the last ResnetBlock of each stage is never executed
                 key = f"up_blocks.{i}.{j}."
                 blk = m.up_blocks[i][j]
-                nxt = engine.emit_resblock(pg, blk, packed, key, srcs, B, li, eb, tb, NE, m.embed_offsets[key])
+                nxt_gn = engine.block_input_gn(pg, m.up_blocks[i][j + 1], f"up_blocks.{i}.{j + 1}.", B, li) if j + 1 < R - 1 else None
+                nxt = engine.emit_resblock(pg, blk, packed, key, a1, srcs, B, li, eb, tb, NE, m.embed_offsets[key], next_gn=nxt_gn)
+                pg.release(a1)
                 for t, _ in srcs:
                     pg.release(t)
                 srcs = [(nxt, co)]
+                a1 = nxt_gn.out if nxt_gn is not None else None
             cur = srcs[0][0]
-            uconv = m.up_blocks[i][m.res_blocks]
-            nxt = pg.alloc((B, lo, co))
+            uconv = m.up_blocks[i][R]
+            last = i + 1 == m.stages
+            if last:  # head GroupNorm (default eps 1e-5, no activation, TrajUNet.py:42-45): the raw tensor is not needed
+                gn_head = m.head[0]
+                a_head = pg.alloc((B, lo, co))
+                gn_up = engine.GnSpec(gn_head, "head.0", 0, co // gn_head.num_groups, ACT_NONE, a_head, co, 0)
+                nxt = None
+            else:
+                gn_up = decoder_input_gn(i + 1, 0)
+                nxt = pg.alloc((B, lo, co))
             pg.conv([engine.Seg(cur, co, co, li, lvirt=lo)], packed[f"up_blocks.{i}.up.w"],
-                    engine.fp32_param(uconv.bias, f"up_blocks.{i}.{m.res_blocks}.bias"), nxt, co, B, lo, co, name=f"up_blocks.{i}.up")
+                    engine.fp32_param(uconv.bias, f"up_blocks.{i}.{R}.bias"), nxt, co, B, lo, co, name=f"up_blocks.{i}.up", gn=gn_up)
             pg.release(cur)
             cur = nxt
-        gn, hconv = m.head[0], m.head[1]
-        a = pg.alloc((B, L, cs[0]))
-        pg.groupnorm(cur, cs[0], a, cs[0], 0, engine.fp32_param(gn.weight, "head.0.weight"), engine.fp32_param(gn.bias, "head.0.bias"), 0,
-                     B, L, cs[0], gn.num_groups, gn.eps, ACT_NONE, name="head.gn")
-        pg.call("head.conv", pg.lib.tdx_head_conv, a.data_ptr(), engine.fp32_param(hconv.weight, "head.1.weight").data_ptr(),
-                engine.fp32_param(hconv.bias, "head.1.bias").data_ptr(), self.eps.data_ptr(), B, L, cs[0], pg.code, keep=[a])
+        hconv = m.head[1]
+        pg.call("head.conv", pg.lib.tdx_head_conv, gn_up.out.data_ptr(), engine.fp32_param(hconv.weight, "head.1.weight").data_ptr(),
+                engine.fp32_param(hconv.bias, "head.1.bias").data_ptr(), self.eps.data_ptr(), B, L, cs[0], pg.code, keep=[gn_up.out])
 
     def load_inputs(self, x, time, cat_attr, num_attr) -> None:
         self.x.copy_(x)

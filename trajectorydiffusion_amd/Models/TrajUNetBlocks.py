@@ -126,7 +126,10 @@ class ResnetBlock(_HipBlock):
         emb = time_attr_embed.detach().reshape(B, self.embed_dim).to(torch.float32).contiguous()
         pg.conv([engine.Seg(emb, self.embed_dim, self.embed_dim, 1, taps=1)], self.embed_proj.weight.detach().reshape(self.out_c, -1),
                 self.embed_proj.bias.detach(), e, self.out_c, B, 1, self.out_c, dtype_code=_lib.TDX_F32, name="embed_proj")
-        out = engine.emit_resblock(pg, self, packed, "", [(_rows(x, dt), self.in_c)], B, L, e, None, self.out_c, 0)
+        xr = _rows(x, dt)
+        gn1 = engine.block_input_gn(pg, self, "", B, L)
+        engine.emit_groupnorm(pg, xr, self.in_c, B, L, gn1, "gn1")
+        out = engine.emit_resblock(pg, self, packed, "", gn1.out, [(xr, self.in_c)], B, L, e, None, self.out_c, 0)
         pg.run()
         return _chan_first(out)
 
@@ -148,14 +151,14 @@ class AttnBlock(_HipBlock):
         out[key + "qkv.w"] = engine.pack_conv_weight(self.qkv_getter[1].weight, dtype)
         out[key + "proj.w"] = engine.pack_conv_weight(self.project_out.weight, dtype)
 
-    def emit(self, pg: engine.Program, packed: Dict[str, torch.Tensor], key: str, x: torch.Tensor, B: int, L: int,
-             ebias, tbias, e_ld: int, e_offs: Tuple[int, int]) -> torch.Tensor:
+    def emit(self, pg: engine.Program, packed: Dict[str, torch.Tensor], key: str, x: torch.Tensor, a1: torch.Tensor, B: int, L: int,
+             ebias, tbias, e_ld: int, e_offs: Tuple[int, int], next_gn=None) -> torch.Tensor:
+        """x raw (B, L, C) and a1 = Swish(GN1_res1(x)); returns the raw output; `next_gn` is applied by res2's last conv."""
         Cn = self.in_c
-        x1 = engine.emit_resblock(pg, self.res1, packed, key + "res1.", [(x, Cn)], B, L, ebias, tbias, e_ld, e_offs[0])
         gn, qkv_conv = self.qkv_getter[0], self.qkv_getter[1]
         a = pg.alloc((B, L, Cn))
-        pg.groupnorm(x1, Cn, a, Cn, 0, engine.fp32_param(gn.weight, key + "qkv_getter.0.weight"),
-                     engine.fp32_param(gn.bias, key + "qkv_getter.0.bias"), 0, B, L, Cn, self.norm_groups, gn.eps, ACT_NONE, name=key + "gn")
+        x1 = engine.emit_resblock(pg, self.res1, packed, key + "res1.", a1, [(x, Cn)], B, L, ebias, tbias, e_ld, e_offs[0],
+                                  next_gn=engine.GnSpec(gn, key + "qkv_getter.0", 0, Cn // self.norm_groups, ACT_NONE, a, Cn, 0))
         qkv = pg.alloc((B, L, 3 * Cn))
         pg.conv([engine.Seg(a, Cn, Cn, L, taps=1)], packed[key + "qkv.w"], engine.fp32_param(qkv_conv.bias, key + "qkv.b"), qkv,
                 3 * Cn, B, L, 3 * Cn, name=key + "qkv")
@@ -164,11 +167,14 @@ class AttnBlock(_HipBlock):
         pg.call(key + "attention", pg.lib.tdx_attention, qkv.data_ptr(), o.data_ptr(), B, L, Cn, pg.code, keep=[qkv, o])
         pg.release(qkv)
         x2 = pg.alloc((B, L, Cn))
+        gn_r2 = engine.block_input_gn(pg, self.res2, key + "res2.", B, L)
         pg.conv([engine.Seg(o, Cn, Cn, L, taps=1)], packed[key + "proj.w"], engine.fp32_param(self.project_out.bias, key + "proj.b"),
-                x2, Cn, B, L, Cn, res=x1, res_ld=Cn, name=key + "proj")
+                x2, Cn, B, L, Cn, res=x1, res_ld=Cn, name=key + "proj", gn=gn_r2)
         pg.release(o)
         pg.release(x1)
-        out = engine.emit_resblock(pg, self.res2, packed, key + "res2.", [(x2, Cn)], B, L, ebias, tbias, e_ld, e_offs[1])
+        out = engine.emit_resblock(pg, self.res2, packed, key + "res2.", gn_r2.out, [(x2, Cn)], B, L, ebias, tbias, e_ld, e_offs[1],
+                                   next_gn=next_gn)
+        pg.release(gn_r2.out)
         pg.release(x2)
         return out
 
@@ -184,6 +190,9 @@ class AttnBlock(_HipBlock):
         bcat = torch.cat([self.res1.embed_proj.bias.detach(), self.res2.embed_proj.bias.detach()]).contiguous()
         e = pg.alloc((B, 2 * Cn), torch.float32)
         pg.conv([engine.Seg(emb, 256, 256, 1, taps=1)], wcat, bcat, e, 2 * Cn, B, 1, 2 * Cn, dtype_code=_lib.TDX_F32, name="embed_proj")
-        out = self.emit(pg, packed, "", _rows(x, dt), B, L, e, None, 2 * Cn, (0, Cn))
+        xr = _rows(x, dt)
+        gn1 = engine.block_input_gn(pg, self.res1, "res1.", B, L)
+        engine.emit_groupnorm(pg, xr, Cn, B, L, gn1, "res1.gn1")
+        out = self.emit(pg, packed, "", xr, gn1.out, B, L, e, None, 2 * Cn, (0, Cn))
         pg.run()
         return _chan_first(out)

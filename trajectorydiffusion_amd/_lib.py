@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("seg", KSeg * 4), ("nseg", _i32), ("dtype", _i32), ("w", _vp), ("bias", _vp), ("ebias", _vp),
                 ("tbias", _vp), ("ebias_ld", _i32), ("ebias_off", _i32), ("res", _vp), ("res_ld", _i32), ("act", _i32),
                 ("out", _vp), ("out_ld", _i32), ("out_off", _i32), ("B", _i32), ("lout", _i32), ("cout", _i32),
-                ("reserved", _i32)]
+                ("reserved", _i32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_ld", _i32), ("gn_off", _i32),
+                ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32)]
 
 
 _SIGNATURES = {
@@ -36,6 +37,7 @@ _SIGNATURES = {
     "tdx_version": (_i32, []),
     "tdx_device_ok": (_i32, []),
     "tdx_conv_gemm": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "tdx_conv_gemm_gn_fusable": (_i32, [C.POINTER(ConvDesc)]),
     "tdx_conv_gemm_force_small": (_i32, [_i32]),
     "tdx_conv_gemm_debug": (_i32, [_i32]),
     "tdx_groupnorm_act": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),

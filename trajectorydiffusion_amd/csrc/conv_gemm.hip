@@ -42,6 +42,12 @@ struct ConvArgs {
   char* out;
   int32_t out_ld, out_off;
   int32_t N, lout, cout, B;
+  int32_t tile_rows;  // rows per row tile of the DMA kernels: 256, or k * L when the GroupNorm epilogue needs whole trajectories
+  const float* gn_gamma;
+  const float* gn_beta;
+  char* gn_out;
+  int32_t gn_ld, gn_off, gn_act, gn_cpg, gn_L;
+  float gn_eps;
   int32_t debug;  // ablation bits for scripts/conv_bench.py: 1 = no loads after the first stage, 2 = no MFMA, 4 = no stores
 };
 
@@ -49,6 +55,7 @@ int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
 int g_debug = 0;
 constexpr int kRowBytes = 128;  // one K-step of one tile row: 64 bf16 / 32 fp32
 constexpr int kThreads = 256;
+constexpr int kDmaThreadsC = 512;
 
 // Run f(integral_constant<int, tap>) for a wave-uniform runtime tap in {0, 1, 2}: every per-tap register array is then
 // indexed by a compile-time constant (a runtime index, or a select between elements, sends the array to scratch).
@@ -141,19 +148,29 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4 (&acc)[MI][NI]
 
 // Epilogue of the DMA kernel: each wave transposes its accumulators through a private LDS patch, 16 rows at a
 // time, so that global traffic is whole 16-byte vectors of contiguous row segments (bias / embed-bias / residual
-// reads and the output store are all coalesced).  WCO = channels per wave tile.
-template <typename T, int MI, int NI, int WCO>
-__device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI][NI], char* patch, int n_base, int co_base, int lane) {
+// reads and the output stores are all coalesced).  WCO = channels per wave tile, TCH = channels per block tile.
+//
+// GN = true additionally applies the CONSUMER's GroupNorm (+ activation) to the finished rows and stores that
+// too (or only that, when p.out is null).  It needs row tiles made of whole trajectories (p.tile_rows = k * L),
+// so every (trajectory, group) statistic is complete inside the workgroup.  Statistics are exact two-pass
+// (mean, then centred squares) and bitwise reproducible: per-row partial sums by xor-shuffles -> LDS table ->
+// fixed-order tree over the L rows.  No atomics.
+template <typename T, int MI, int NI, int WCO, int TCH, bool GN>
+__device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI][NI], char* smem, int wave, int wr, int wc, int lane,
+                                             int n0, int co0) {
   constexpr int VEC = 16 / (int)sizeof(T);      // output elements per 16-byte store
   constexpr int STRIDE = WCO * 4 + 16;          // fp32 patch row, padded: conflict-free ds_write_b128
+  constexpr int PATCH = 16 * STRIDE;
   constexpr int CPR = WCO / VEC;                // 16-byte output chunks per row
   constexpr int RPP = 64 / CPR;                 // rows per pass
   constexpr int NP = 16 / RPP;
   static_assert(CPR <= 64 && NP >= 1, "wave tile too wide");
+  char* patch = smem + wave * PATCH;
   const int fr = lane & 15, fq = lane >> 4;
   const int c = lane % CPR, r0 = lane / CPR;
-  const int co = co_base + c * VEC;
+  const int co = co0 + wc * WCO + c * VEC;
   const bool co_ok = co < p.cout;
+  const int n_end = n0 + p.tile_rows < p.N ? n0 + p.tile_rows : p.N;
   float bs[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) bs[j] = 0.f;
@@ -165,6 +182,48 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
       for (int j = 0; j < VEC; ++j) bs[j] += p.tbias[p.ebias_off + co + j];
   }
+  // GroupNorm bookkeeping (GN only)
+  const int cpg = GN ? p.gn_cpg : VEC;
+  const int GT = TCH / cpg;                          // groups per block tile
+  const int LPG = cpg >= VEC ? cpg / VEC : 1;        // lanes that share one group within a row
+  const bool two = cpg < VEC;                        // two groups inside one 16-byte vector (cpg == VEC / 2)
+  const int g0 = (wc * WCO + c * VEC) / cpg;         // this lane's (first) group inside the block tile
+  float* rs = reinterpret_cast<float*>(smem + 8 * PATCH);   // [256 rows][GT] per-row partial sums
+  float* tab_mean = rs + 256 * GT;                            // [trajectories in tile][GT]
+  float* tab_var = tab_mean + (256 / p.gn_L + 1) * GT;
+  float r[GN ? NI : 1][GN ? NP : 1][VEC];
+  auto row_partial = [&](const float (&v)[VEC], int row_local) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC / 2; ++j) {
+      s0 += v[j];
+      s1 += v[VEC / 2 + j];
+    }
+    if (!two) s0 += s1;
+    for (int o = 1; o < LPG; o <<= 1) s0 += __shfl_xor(s0, o, 64);
+    if ((c & (LPG - 1)) == 0) {
+      rs[row_local * GT + g0] = s0;
+      if (two) rs[row_local * GT + g0 + 1] = s1;
+    }
+  };
+  // fixed-order reduction of the per-row partials over each trajectory's L rows -> tab[traj][group] * scale
+  auto reduce_rows = [&](float* tab, float scale) {
+    const int L = p.gn_L, E = (p.tile_rows / L) * GT;
+    int tpe = 64;
+    while (tpe > 1 && E * tpe > kDmaThreadsC) tpe >>= 1;
+    const int tid = wave * 64 + lane, sub = tid & (tpe - 1), per_round = kDmaThreadsC / tpe;
+    for (int e0 = 0; e0 < E; e0 += per_round) {
+      const int e = e0 + tid / tpe;
+      float sum = 0.f;
+      if (e < E) {
+        const int traj = e / GT, g = e - traj * GT;
+        for (int l = sub; l < L; l += tpe) sum += rs[(traj * L + l) * GT + g];
+      }
+      for (int o = 1; o < tpe; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      if (e < E && sub == 0) tab[e] = sum * scale;
+    }
+  };
+
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -173,7 +232,8 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int row = r0 + RPP * i;
-      const int n = n_base + ni * 16 + row;
+      const int row_local = wr * 64 + ni * 16 + row;
+      const int n = n0 + row_local;
       float v[VEC];
 #pragma unroll
       for (int h = 0; h < VEC / 4; ++h) {
@@ -181,7 +241,8 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[h * 4 + j] = t[j];
       }
-      if (n < p.N && co_ok) {
+      const bool live = n < n_end && co_ok;
+      if (live) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] += bs[j];
         if (p.ebias) {
@@ -201,9 +262,63 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
           for (int j = 0; j < VEC; ++j) v[j] += rv[j];
         }
-        *reinterpret_cast<u32x4*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * sizeof(T)) = Elem<T>::pack(v);
+        if (p.out) *reinterpret_cast<u32x4*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * sizeof(T)) = Elem<T>::pack(v);
+      }
+      if constexpr (GN) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) r[ni][i][j] = live ? v[j] : 0.f;
+        row_partial(r[ni][i], row_local);
       }
     }
+  }
+  if constexpr (GN) {
+    const float inv_cnt = 1.0f / ((float)cpg * (float)p.gn_L);
+    __syncthreads();
+    reduce_rows(tab_mean, inv_cnt);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int row_local = wr * 64 + ni * 16 + r0 + RPP * i;
+        const int tj = (row_local < p.tile_rows ? row_local : 0) / p.gn_L;
+        const float m0 = tab_mean[tj * GT + g0], m1 = two ? tab_mean[tj * GT + g0 + 1] : m0;
+        float d[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float t = r[ni][i][j] - (j < VEC / 2 ? m0 : m1);
+          d[j] = t * t;
+        }
+        row_partial(d, row_local);
+      }
+    __syncthreads();
+    reduce_rows(tab_var, inv_cnt);
+    __syncthreads();
+    float gm[VEC], bt[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      gm[j] = co_ok ? p.gn_gamma[co + j] : 0.f;
+      bt[j] = co_ok ? p.gn_beta[co + j] : 0.f;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int row_local = wr * 64 + ni * 16 + r0 + RPP * i;
+        const int n = n0 + row_local;
+        if (!(n < n_end && co_ok)) continue;
+        const int tj = row_local / p.gn_L;
+        const float m0 = tab_mean[tj * GT + g0], m1 = two ? tab_mean[tj * GT + g0 + 1] : m0;
+        const float q0 = rsqrtf(tab_var[tj * GT + g0] + p.gn_eps), q1 = two ? rsqrtf(tab_var[tj * GT + g0 + 1] + p.gn_eps) : q0;
+        float y[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float m = j < VEC / 2 ? m0 : m1, q = j < VEC / 2 ? q0 : q1;
+          const float sc = q * gm[j];
+          y[j] = tdx_act(fmaf(r[ni][i][j], sc, bt[j] - m * sc), p.gn_act);
+        }
+        *reinterpret_cast<u32x4*>(p.gn_out + ((size_t)n * p.gn_ld + p.gn_off + co) * sizeof(T)) = Elem<T>::pack(y);
+      }
   }
 }
 
@@ -422,7 +537,7 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const u3
       : "memory");
 }
 
-template <typename T, int TC, bool WIN>
+template <typename T, int TC, bool WIN, bool GN>
 __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   constexpr int TR = kDmaRows;
@@ -444,7 +559,7 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
   const int nco = (p.cout + TC - 1) / TC;
   const int xcd = blockIdx.x & 7, jt = blockIdx.x >> 3;
   const int row_tile = (jt / nco) * 8 + xcd;
-  const int n0 = row_tile * TR;
+  const int n0 = row_tile * p.tile_rows;
   if (n0 >= p.N) return;
   const int co0 = (jt % nco) * TC;
   const int fr = lane & 15, fq = lane >> 4;
@@ -513,9 +628,10 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     const int b0 = n0 / p.lout;
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int n = n0 + 8 * (wave + 8 * i) + r8;
+      const int i_loc = 8 * (wave + 8 * i) + r8;
+      const int n = n0 + i_loc;
       const int b = n / p.lout;
-      rb_b[i] = n < p.N ? b - b0 : -1;
+      rb_b[i] = (n < p.N && i_loc < p.tile_rows) ? b - b0 : -1;
       rb_l[i] = n - b * p.lout;
     }
   }
@@ -587,8 +703,9 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
   if constexpr (WIN) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wr * 64 + ni * 16 + fr;
-      wl[ni] = n < p.N ? n % p.lout : -1;
+      const int i_loc = wr * 64 + ni * 16 + fr;
+      const int n = n0 + i_loc;
+      wl[ni] = (n < p.N && i_loc < p.tile_rows) ? n % p.lout : -1;
     }
     cp_setup();
     if (tid < 16)  // the two zero rows (never touched by the DMA)
@@ -661,51 +778,69 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     return;
   }
   __syncthreads();  // every wave is done reading the stage buffers; reuse them as per-wave transpose patches
-  constexpr int WCO = TC / 2;
-  epilogue_lds<T, MI, NI, WCO>(p, acc, smem + wave * (16 * (WCO * 4 + 16)), n0 + wr * 64, co0 + wc * WCO, lane);
+  epilogue_lds<T, MI, NI, TC / 2, TC, GN>(p, acc, smem, wave, wr, wc, lane, n0, co0);
 #endif
 }
 
-template <typename T, int TC, bool WIN>
+constexpr size_t dma_lds_bytes(int tc, bool win) {
+  return win ? 2 * (size_t)tc * kRowBytes + 2 * (size_t)kWinBytes : 2 * (size_t)(kDmaRows + tc) * kRowBytes;
+}
+// LDS the GroupNorm epilogue needs: 8 transpose patches + per-row partials + mean/var tables
+inline size_t gn_lds_bytes(int tc, int cpg, int L) {
+  const size_t gt = tc / cpg;
+  return 8 * 16 * (size_t)(tc / 2 * 4 + 16) + 256 * gt * 4 + 2 * (size_t)(256 / L + 1) * gt * 4;
+}
+
+template <typename T, int TC, bool WIN, bool GN>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
-  const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + kDmaRows - 1) / kDmaRows;
+  const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + a.tile_rows - 1) / a.tile_rows;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
-  size_t lds = WIN ? 2 * (size_t)TC * kRowBytes + 2 * (size_t)kWinBytes : 2 * (size_t)(kDmaRows + TC) * kRowBytes;
+  size_t lds = dma_lds_bytes(TC, WIN);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, WIN, GN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_dma: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC, WIN>), grid, dim3(kDmaThreads), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC, WIN, GN>), grid, dim3(kDmaThreads), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_dma_kernel");
   return TDX_OK;
 }
 
 template <typename T>
-int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, bool win) {
-  if (win) return tc == 256 ? launch_dma<T, 256, true>(a, st) : launch_dma<T, 128, true>(a, st);
-  return tc == 256 ? launch_dma<T, 256, false>(a, st) : launch_dma<T, 128, false>(a, st);
+int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, bool win, bool gn) {
+  if (gn) {
+    if (win) return tc == 256 ? launch_dma<T, 256, true, true>(a, st) : launch_dma<T, 128, true, true>(a, st);
+    return tc == 256 ? launch_dma<T, 256, false, true>(a, st) : launch_dma<T, 128, false, true>(a, st);
+  }
+  if (win) return tc == 256 ? launch_dma<T, 256, true, false>(a, st) : launch_dma<T, 128, true, false>(a, st);
+  return tc == 256 ? launch_dma<T, 256, false, false>(a, st) : launch_dma<T, 128, false, false>(a, st);
 }
 
 }  // namespace
 
-extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
+// Validate a descriptor, translate it to kernel arguments and choose the kernel.  kind: 0 = register-staged
+// 128x128, 1 = LDS-DMA gather, 2 = LDS-DMA window; tc = channel tile of the DMA kernels; gn = fused GroupNorm.
+struct Choice { int kind, tc; bool gn; };
+
+static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   TDX_CHECK_ARG(d != nullptr, "tdx_conv_gemm: null descriptor");
   TDX_CHECK_ARG(d->dtype == TDX_F32 || d->dtype == TDX_BF16, "tdx_conv_gemm: bad dtype %d", d->dtype);
   const int es = d->dtype == TDX_F32 ? 4 : 2;
   const int vec = 16 / es, bk = kRowBytes / es;
+  const bool want_gn = d->gn_gamma != nullptr;
   TDX_CHECK_ARG(d->nseg >= 1 && d->nseg <= 4, "tdx_conv_gemm: nseg=%d not in [1,4]", d->nseg);
   TDX_CHECK_ARG(d->B > 0 && d->lout > 0 && d->cout > 0, "tdx_conv_gemm: empty problem B=%d lout=%d cout=%d", d->B, d->lout, d->cout);
   TDX_CHECK_ARG((int64_t)d->B * d->lout < (1ll << 31), "tdx_conv_gemm: B*lout overflows int32");
-  TDX_CHECK_ARG(d->cout % 4 == 0 && d->out_off % 4 == 0 && d->out_ld % 4 == 0 && d->out_off + d->cout <= d->out_ld,
-                "tdx_conv_gemm: cout/out_off/out_ld must be multiples of 4 and fit (cout=%d off=%d ld=%d)", d->cout, d->out_off, d->out_ld);
-  TDX_CHECK_ARG(d->w && d->out, "tdx_conv_gemm: null w/out");
+  TDX_CHECK_ARG(d->w && (d->out || want_gn), "tdx_conv_gemm: null w/out");
+  TDX_CHECK_ARG(d->cout % 4 == 0, "tdx_conv_gemm: cout=%d must be a multiple of 4", d->cout);
+  TDX_CHECK_ARG(!d->out || (d->out_off % 4 == 0 && d->out_ld % 4 == 0 && d->out_off + d->cout <= d->out_ld),
+                "tdx_conv_gemm: out_off/out_ld must be multiples of 4 and fit (cout=%d off=%d ld=%d)", d->cout, d->out_off, d->out_ld);
   TDX_CHECK_ARG(!d->res || (d->res_ld % 4 == 0 && d->res_ld >= d->cout), "tdx_conv_gemm: bad res_ld %d", d->res_ld);
   TDX_CHECK_ARG(!(d->ebias || d->tbias) || (d->ebias_off % 4 == 0 && d->ebias_ld % 4 == 0), "tdx_conv_gemm: ebias_off/ld must be multiples of 4");
   TDX_CHECK_ARG(d->act >= TDX_ACT_NONE && d->act <= TDX_ACT_SWISH, "tdx_conv_gemm: bad act %d", d->act);
-  ConvArgs a{};
+  a = ConvArgs{};
   int k = 0, steps = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const tdx_kseg& s = d->seg[i];
@@ -744,7 +879,9 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   a.cout = d->cout;
   a.B = d->B;
   a.debug = g_debug;
-  hipStream_t st = (hipStream_t)stream;
+  a.tile_rows = kDmaRows;
+  a.gn_L = d->lout;
+  a.gn_cpg = vec;
   // LDS-DMA kernels: whole 128-byte channel blocks only, 32-bit in-tile offsets, 16-byte epilogue vectors, and
   // enough 256-row tiles to fill the chip.  Window variant: every segment stride 1 on an un-resampled source.
   bool dma_ok = !(g_force & 1), win_ok = !(g_force & 2);
@@ -754,19 +891,57 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
     win_ok = win_ok && s.stride == 1 && s.lvirt == s.lin && s.lin == d->lout && ((int64_t)(kDmaRows + 16) * s.src_ld * es < (1ll << 31));
   }
   dma_ok = dma_ok && (int64_t)kDmaRows * k * es < (1ll << 31);
-  dma_ok = dma_ok && d->cout % vec == 0 && d->out_off % vec == 0 && d->out_ld % vec == 0 && (!d->res || d->res_ld % vec == 0);
+  dma_ok = dma_ok && d->cout % vec == 0 && (!d->out || (d->out_off % vec == 0 && d->out_ld % vec == 0)) && (!d->res || d->res_ld % vec == 0);
   const int tc = (d->cout % 256 == 0) ? 256 : 128;
   const int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
-  if (dma_ok && tiles >= 128) {
-    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, tc, win_ok);
-    return dispatch_dma<__bf16>(a, st, tc, win_ok);
+  ch = Choice{0, tc, false};
+  if (want_gn) {
+    TDX_CHECK_ARG(d->gn_beta && d->gn_out, "tdx_conv_gemm: fused GroupNorm needs gn_beta and gn_out");
+    TDX_CHECK_ARG(d->gn_act >= TDX_ACT_NONE && d->gn_act <= TDX_ACT_SWISH, "tdx_conv_gemm: bad gn_act %d", d->gn_act);
+    TDX_CHECK_ARG(d->gn_cpg > 0 && d->cout % d->gn_cpg == 0, "tdx_conv_gemm: gn_cpg=%d must divide cout=%d", d->gn_cpg, d->cout);
+    const int cpg = d->gn_cpg;
+    bool ok = dma_ok && !(g_force & 4) && d->lout <= kDmaRows && cpg >= 4 && cpg >= vec / 2 && (cpg & (cpg - 1)) == 0 && cpg <= tc / 2 &&
+              d->gn_off % vec == 0 && d->gn_ld % vec == 0 && d->gn_off + d->cout <= d->gn_ld;
+    ok = ok && gn_lds_bytes(tc, cpg, d->lout) <= dma_lds_bytes(tc, win_ok);
+    if (!ok) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_conv_gemm: this shape cannot fuse the GroupNorm (lout=%d cout=%d cpg=%d): run tdx_groupnorm_act", d->lout, d->cout, cpg);
+    a.tile_rows = (kDmaRows / d->lout) * d->lout;
+    a.gn_gamma = d->gn_gamma;
+    a.gn_beta = d->gn_beta;
+    a.gn_out = (char*)d->gn_out;
+    a.gn_ld = d->gn_ld;
+    a.gn_off = d->gn_off;
+    a.gn_act = d->gn_act;
+    a.gn_cpg = cpg;
+    a.gn_eps = d->gn_eps;
+    ch = Choice{win_ok ? 2 : 1, tc, true};
+  } else if (dma_ok && tiles >= 128) {
+    ch = Choice{win_ok ? 2 : 1, tc, false};
+  }
+  return TDX_OK;
+}
+
+extern "C" int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* d) {
+  ConvArgs a;
+  Choice ch;
+  return d && d->gn_gamma && plan_conv(d, a, ch) == TDX_OK && ch.gn ? 1 : 0;
+}
+
+extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
+  ConvArgs a;
+  Choice ch;
+  const int rc = plan_conv(d, a, ch);
+  if (rc != TDX_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (ch.kind != 0) {
+    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, ch.tc, ch.kind == 2, ch.gn);
+    return dispatch_dma<__bf16>(a, st, ch.tc, ch.kind == 2, ch.gn);
   }
   if (d->dtype == TDX_F32) return launch<float, 128, 128>(a, st);
   return launch<__bf16, 128, 128>(a, st);
 }
 
 // Test hooks (not part of the reference-facing surface).
-// force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant.
+// force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable.
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   g_force = bits;
   return TDX_OK;

@@ -91,10 +91,12 @@ class Program:
     def _add(self, name: str, fn, *args) -> None:
         self.ops.append((name, fn, args))
 
-    def conv(self, segs: Sequence[Seg], w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, out_ld: int,
+    def conv(self, segs: Sequence[Seg], w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor], out_ld: int,
              B: int, lout: int, cout: int, out_off: int = 0, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
              res_ld: int = 0, ebias: Optional[torch.Tensor] = None, tbias: Optional[torch.Tensor] = None, ebias_ld: int = 0,
-             ebias_off: int = 0, dtype_code: Optional[int] = None, name: str = "conv") -> None:
+             ebias_off: int = 0, dtype_code: Optional[int] = None, name: str = "conv", gn: Optional["GnSpec"] = None) -> None:
+        """Record one tdx_conv_gemm.  `gn` = the consumer's GroupNorm(+act): fused into the conv epilogue when the library
+        can (then `out` may be None = the raw tensor is not needed), else run as a separate tdx_groupnorm_act."""
         d = ConvDesc()
         ktot = 0
         for i, s in enumerate(segs):
@@ -111,11 +113,30 @@ class Program:
         d.w, d.bias = w.data_ptr(), _lib.ptr(bias)
         d.ebias, d.tbias, d.ebias_ld, d.ebias_off = _lib.ptr(ebias), _lib.ptr(tbias), ebias_ld, ebias_off
         d.res, d.res_ld, d.act = _lib.ptr(res), res_ld, act
-        d.out, d.out_ld, d.out_off = out.data_ptr(), out_ld, out_off
+        d.out, d.out_ld, d.out_off = _lib.ptr(out), out_ld, out_off
         d.B, d.lout, d.cout = B, lout, cout
+        fused, tmp = False, None
+        if gn is not None:
+            d.gn_gamma, d.gn_beta = gn.gamma.data_ptr() + 4 * gn.p_off, gn.beta.data_ptr() + 4 * gn.p_off
+            d.gn_out, d.gn_ld, d.gn_off, d.gn_act, d.gn_cpg, d.gn_eps = gn.out.data_ptr(), gn.out_ld, gn.out_off, gn.act, gn.cpg, gn.eps
+            fused = bool(self.lib.tdx_conv_gemm_gn_fusable(C.byref(d)))
+            if not fused:
+                d.gn_gamma = None
+                if out is None:  # the separate GroupNorm kernel needs the raw tensor
+                    tmp = out = self.alloc((B, lout, cout))
+                    d.out, d.out_ld, d.out_off = out.data_ptr(), cout, 0
+                    out_ld, out_off = cout, 0
+            self.keep.extend([gn.gamma, gn.beta, gn.out])
         self.keep.extend([d, w, bias, out, res, ebias, tbias])
         self._add(name, self.lib.tdx_conv_gemm, C.byref(d))
         self.flops[len(self.ops) - 1] = 2.0 * B * lout * cout * ktot
+        if gn is not None and not fused:
+            if out_off != 0:
+                raise TdxError(f"{name}: unfused GroupNorm fallback needs the raw tensor at channel offset 0")
+            self.groupnorm(out, out_ld, gn.out, gn.out_ld, gn.out_off, gn.gamma, gn.beta, gn.p_off, B, lout, cout, cout // gn.cpg,
+                           gn.eps, gn.act, name=name + ".gn")
+            if tmp is not None:
+                self.release(tmp)
 
     def groupnorm(self, x: torch.Tensor, x_ld: int, out: torch.Tensor, out_ld: int, out_off: int, gamma: torch.Tensor,
                   beta: torch.Tensor, p_off: int, B: int, L: int, Cn: int, groups: int, eps: float, act: int,
@@ -158,57 +179,61 @@ def fp32_param(p: torch.Tensor, name: str) -> torch.Tensor:
     return p.detach()
 
 
-class ResSpec:
-    """Everything the executor needs from one ResnetBlock (parameters by reference)."""
+class GnSpec:
+    """A consumer's GroupNorm(+act) to be applied to a producer's output rows: parameters (gamma/beta fp32, first
+    channel p_off), channels per group, and where the normalised rows go."""
+    __slots__ = ("gamma", "beta", "p_off", "cpg", "eps", "act", "out", "out_ld", "out_off")
 
-    def __init__(self, blk, e_off: int):
-        self.blk, self.e_off = blk, e_off
-        self.cin, self.cout = blk.in_c, blk.out_c
+    def __init__(self, gn_module, name: str, p_off: int, cpg: int, act: int, out: torch.Tensor, out_ld: int, out_off: int):
+        self.gamma, self.beta = fp32_param(gn_module.weight, name + ".weight"), fp32_param(gn_module.bias, name + ".bias")
+        self.p_off, self.cpg, self.eps, self.act = p_off, cpg, gn_module.eps, act
+        self.out, self.out_ld, self.out_off = out, out_ld, out_off
 
 
-def emit_resblock(pg: Program, blk, packed: Dict[str, torch.Tensor], key: str, srcs: Sequence[Tuple[torch.Tensor, int]],
-                  B: int, L: int, ebias: Optional[torch.Tensor], tbias: Optional[torch.Tensor], e_ld: int, e_off: int,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ResnetBlock (Models/TrajUNetBlocks.py:92-99) over channels-last sources.
+def block_input_gn(pg: Program, blk, key: str, B: int, L: int, part_off: int = 0, a1: Optional[torch.Tensor] = None) -> GnSpec:
+    """GnSpec of a ResnetBlock's first GroupNorm+Swish (Models/TrajUNetBlocks.py:75-76) for the channel slice that starts at
+    part_off of its (possibly concatenated) input; allocates the activated buffer (B, L, in_c) unless given."""
+    if a1 is None:
+        a1 = pg.alloc((B, L, blk.in_c))
+    return GnSpec(blk.stage1[0], key + "stage1.0", part_off, blk.in_c // blk.norm_groups, ACT_SWISH, a1, blk.in_c, part_off)
 
-    `srcs` is [(tensor (B, L, C_k), C_k), ...]: more than one entry is the decoder's channel concat
-    (Models/TrajUNet.py:90), which is never materialised for the raw tensor: GroupNorm writes its
-    activated output into one concatenated buffer and the 1x1 shortcut reads each source as its
-    own K-segment.
+
+def emit_groupnorm(pg: Program, src: torch.Tensor, c: int, B: int, L: int, gn: GnSpec, name: str) -> None:
+    """Stand-alone GroupNorm kernel for a producer that is not a conv GEMM (stem) or a second consumer (decoder skip half)."""
+    if c % gn.cpg:
+        raise TdxError(f"{name}: {c} channels do not hold whole GroupNorm groups of {gn.cpg}")
+    pg.groupnorm(src, c, gn.out, gn.out_ld, gn.out_off, gn.gamma, gn.beta, gn.p_off, B, L, c, c // gn.cpg, gn.eps, gn.act, name=name)
+
+
+def emit_resblock(pg: Program, blk, packed: Dict[str, torch.Tensor], key: str, a1: torch.Tensor,
+                  srcs: Sequence[Tuple[torch.Tensor, int]], B: int, L: int, ebias: Optional[torch.Tensor],
+                  tbias: Optional[torch.Tensor], e_ld: int, e_off: int, want_raw: bool = True,
+                  next_gn: Optional[GnSpec] = None) -> Optional[torch.Tensor]:
+    """ResnetBlock (Models/TrajUNetBlocks.py:92-99) over channels-last tensors.
+
+    a1   = Swish(GroupNorm(x)) (B, L, in_c), produced by whoever produced x (fused into that conv's epilogue);
+    srcs = the raw x as [(tensor (B, L, C_k), C_k), ...]: more than one entry is the decoder's channel concat
+           (Models/TrajUNet.py:90), never materialised: the 1x1 shortcut reads each source as its own K-segment.
+    conv1's epilogue applies this block's second GroupNorm+Swish (its raw output is never stored); conv2's epilogue adds the
+    shortcut/residual, stores the raw output when `want_raw`, and applies the NEXT consumer's GroupNorm (`next_gn`).
     """
     cin = sum(c for _, c in srcs)
     cout = blk.out_c
     if cin != blk.in_c:
         raise TdxError(f"{key}: sources carry {cin} channels, block expects {blk.in_c}")
-    groups = blk.norm_groups
-    cpg = cin // groups
-    gn1, conv1 = blk.stage1[0], blk.stage1[2]
-    gn2, conv2 = blk.stage2[0], blk.stage2[3]
-    a1 = pg.alloc((B, L, cin))
-    off = 0
-    for src, c in srcs:
-        if c % cpg:
-            raise TdxError(f"{key}: concat boundary at channel {off + c} splits a GroupNorm group of {cpg}")
-        pg.groupnorm(src, c, a1, cin, off, fp32_param(gn1.weight, key + "stage1.0.weight"), fp32_param(gn1.bias, key + "stage1.0.bias"),
-                     off, B, L, c, c // cpg, gn1.eps, ACT_SWISH, name=key + "gn1")
-        off += c
-    h = pg.alloc((B, L, cout))
-    pg.conv([Seg(a1, cin, cin, L)], packed[key + "conv1.w"], fp32_param(conv1.bias, key + "stage1.2.bias"), h, cout, B, L, cout,
-            ebias=ebias, tbias=tbias, ebias_ld=e_ld, ebias_off=e_off, name=key + "conv1")
-    pg.release(a1)
+    conv1, gn2, conv2 = blk.stage1[2], blk.stage2[0], blk.stage2[3]
     a2 = pg.alloc((B, L, cout))
-    pg.groupnorm(h, cout, a2, cout, 0, fp32_param(gn2.weight, key + "stage2.0.weight"), fp32_param(gn2.bias, key + "stage2.0.bias"),
-                 0, B, L, cout, groups, gn2.eps, ACT_SWISH, name=key + "gn2")
-    pg.release(h)
-    if out is None:
-        out = pg.alloc((B, L, cout))
+    pg.conv([Seg(a1, cin, cin, L)], packed[key + "conv1.w"], fp32_param(conv1.bias, key + "stage1.2.bias"), None, cout, B, L, cout,
+            ebias=ebias, tbias=tbias, ebias_ld=e_ld, ebias_off=e_off, name=key + "conv1",
+            gn=GnSpec(gn2, key + "stage2.0", 0, cout // blk.norm_groups, ACT_SWISH, a2, cout, 0))
+    out = pg.alloc((B, L, cout)) if (want_raw or next_gn is None) else None
     segs = [Seg(a2, cout, cout, L)]
     if blk.has_shortcut:
         segs += [Seg(src, c, c, L, taps=1) for src, c in srcs]
-        pg.conv(segs, packed[key + "conv2.w"], packed[key + "conv2.b"], out, cout, B, L, cout, name=key + "conv2")
+        pg.conv(segs, packed[key + "conv2.w"], packed[key + "conv2.b"], out, cout, B, L, cout, name=key + "conv2", gn=next_gn)
     else:
         pg.conv(segs, packed[key + "conv2.w"], fp32_param(conv2.bias, key + "stage2.3.bias"), out, cout, B, L, cout,
-                res=srcs[0][0], res_ld=cin, name=key + "conv2")
+                res=srcs[0][0], res_ld=cin, name=key + "conv2", gn=next_gn)
     pg.release(a2)
     return out
 

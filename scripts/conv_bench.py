@@ -14,6 +14,9 @@ from trajectorydiffusion_amd import _lib, engine  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--debug", type=int, nargs="*", default=[0])
 ap.add_argument("--small", action="store_true")
+ap.add_argument("--gn", action="store_true", help="fuse a consumer GroupNorm+Swish into the epilogue")
+ap.add_argument("--noraw", action="store_true")
+ap.add_argument("--gnact", type=int, default=2)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
@@ -33,7 +36,15 @@ for name, L, ci, co, k in SHAPES:
     bias = torch.randn(co, device="cuda")
     out = torch.empty((B, L, co), device="cuda", dtype=dt)
     pg = engine.Program(torch.device("cuda"), dt)
-    pg.conv([engine.Seg(x, ci, ci, L, taps=k)], w, bias, out, co, B, L, co)
+    gn = None
+    if a.gn:
+        class H:
+            weight, bias, eps = torch.ones(co, device="cuda"), torch.zeros(co, device="cuda"), 1e-6
+        y = torch.empty((B, L, co), device="cuda", dtype=dt)
+        gn = engine.GnSpec(H, "h", 0, co // 32, a.gnact, y, co, 0)
+    pg.conv([engine.Seg(x, ci, ci, L, taps=k)], w, bias, None if a.noraw else out, co, B, L, co, gn=gn)
+    if len(pg.ops) != 1:
+        continue
     fl = 2.0 * B * L * co * k * ci
     cells = []
     for d in a.debug:

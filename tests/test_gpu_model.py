@@ -46,6 +46,23 @@ def test_forward_fp32_matches_reference_golden(model, golden_dir, tag, B, L):
     assert rel(eps, g[f"{tag}/eps"]) < FP32_TOL
 
 
+def test_forward_with_fused_groupnorm_epilogues(model, golden_dir, monkeypatch):
+    """Same forward with every conv applying its consumer's GroupNorm in its own epilogue (opt-in dataflow)."""
+    from trajectorydiffusion_amd import engine
+    g = np.load(os.path.join(golden_dir, "forward.npz"))
+    x, t, cat, num = synth_inputs(4, 200, T_MODEL, seed=1)
+    monkeypatch.setattr(engine, "FUSE_GN_DEFAULT", True)
+    model._programs.clear()
+    try:
+        model.set_compute_dtype(torch.float32)
+        eps = model(x.cuda(), t.cuda(), cat.cuda(), num.cuda()).cpu()
+        prog = model.program(4, 200, torch.device("cuda", 0))
+        assert sum(1 for n, _, _ in prog.pg.ops if n.endswith("gn1") or n.endswith(".gn") or "gn1.skip" in n) == 5
+        assert rel(eps, g["B4_L200/eps"]) < FP32_TOL
+    finally:
+        model._programs.clear()
+
+
 def test_forward_bf16_within_tolerance(model, golden_dir):
     g = np.load(os.path.join(golden_dir, "forward.npz"))
     x, t, cat, num = synth_inputs(4, 200, T_MODEL, seed=1)

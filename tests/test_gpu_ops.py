@@ -198,6 +198,7 @@ def test_conv_with_fused_consumer_groupnorm(dt, B, L, Ci, Co, cpg, act, raw):
 
     def run():
         pg = engine.Program(torch.device("cuda"), dt)
+        pg.fuse_gn = True
         out = torch.full((B, L, Co), float("nan"), device="cuda", dtype=dt) if raw else None
         y = torch.zeros((B, L, Co + 16), device="cuda", dtype=dt)
         spec = engine.GnSpec(Holder, "t", Co, cpg, act, y, Co + 16, 16)
@@ -234,6 +235,7 @@ def test_conv_fused_groupnorm_falls_back_when_trajectory_exceeds_tile():
     class Holder:
         weight, bias, eps = torch.ones(C).cuda(), torch.zeros(C).cuda(), 1e-6
     pg = engine.Program(torch.device("cuda"), torch.float32)
+    pg.fuse_gn = True
     y = torch.zeros((B, L, C), device="cuda")
     pg.conv([engine.Seg(rows(x, torch.float32), C, C, L)], engine.pack_conv_weight(w.cuda(), torch.float32), None, None, C, B, L, C,
             gn=engine.GnSpec(Holder, "t", 0, 4, 0, y, C, 0))

@@ -56,6 +56,7 @@ int g_debug = 0;
 constexpr int kRowBytes = 128;  // one K-step of one tile row: 64 bf16 / 32 fp32
 constexpr int kThreads = 256;
 constexpr int kDmaThreadsC = 512;
+constexpr int kEbMaxTraj = 24;  // embed-bias rows staged in LDS per tile (trajectories of >= 11 rows)
 
 // Run f(integral_constant<int, tap>) for a wave-uniform runtime tap in {0, 1, 2}: every per-tap register array is then
 // indexed by a compile-time constant (a runtime index, or a select between elements, sends the array to scratch).
@@ -182,6 +183,28 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
       for (int j = 0; j < VEC; ++j) bs[j] += p.tbias[p.ebias_off + co + j];
   }
+  // Everything the epilogue reads from global memory is requested up front, so the 16 transpose passes below never
+  // wait on a load of their own: residual vectors go to registers, the tile's embed-bias rows to LDS (one row per
+  // trajectory touched by the tile), GroupNorm parameters to registers.
+  u32x4 resv[NI][NP];
+  if (p.res) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
+        resv[ni][i] = (n < n_end && co_ok) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * sizeof(T))
+                                           : (u32x4){0u, 0u, 0u, 0u};
+      }
+  }
+  float gm[VEC], bt[VEC];
+  if constexpr (GN) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      gm[j] = co_ok ? p.gn_gamma[co + j] : 0.f;
+      bt[j] = co_ok ? p.gn_beta[co + j] : 0.f;
+    }
+  }
   // GroupNorm bookkeeping (GN only)
   const int cpg = GN ? p.gn_cpg : VEC;
   const int GT = TCH / cpg;                          // groups per block tile
@@ -191,6 +214,33 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   float* rs = reinterpret_cast<float*>(smem + 8 * PATCH);   // [256 rows][GT] per-row partial sums
   float* tab_mean = rs + 256 * GT;                            // [trajectories in tile][GT]
   float* tab_var = tab_mean + (256 / p.gn_L + 1) * GT;
+  // [trajectories touched][TCH] staged embed-bias rows
+  float* eb_lds = GN ? tab_var + (256 / p.gn_L + 1) * GT : reinterpret_cast<float*>(smem + 8 * PATCH);
+  const int b_first = n0 / p.lout;
+  const int ntraj = (n_end - 1) / p.lout - b_first + 1;
+  const bool eb_staged = p.ebias && ntraj <= kEbMaxTraj;
+  constexpr int EBR = (kEbMaxTraj * (TCH / 4) + kDmaThreadsC - 1) / kDmaThreadsC;  // float4 slots per thread
+  f32x4 ebv[EBR];
+  const int tid_e = wave * 64 + lane;
+  if (eb_staged) {
+#pragma unroll
+    for (int k = 0; k < EBR; ++k) {
+      const int idx = tid_e + k * kDmaThreadsC;
+      const int t = idx / (TCH / 4), q4 = idx - t * (TCH / 4);
+      const int cc = co0 + q4 * 4;
+      ebv[k] = (t < ntraj && cc < p.cout) ? *reinterpret_cast<const f32x4*>(p.ebias + (size_t)(b_first + t) * p.ebias_ld + p.ebias_off + cc)
+                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();  // every wave is done reading the stage buffers: from here on LDS is epilogue scratch
+  if (eb_staged) {
+#pragma unroll
+    for (int k = 0; k < EBR; ++k) {
+      const int idx = tid_e + k * kDmaThreadsC;
+      if (idx < ntraj * (TCH / 4)) *reinterpret_cast<f32x4*>(eb_lds + idx * 4) = ebv[k];
+    }
+    __syncthreads();
+  }
   float r[GN ? NI : 1][GN ? NP : 1][VEC];
   auto row_partial = [&](const float (&v)[VEC], int row_local) {
     float s0 = 0.f, s1 = 0.f;
@@ -246,7 +296,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] += bs[j];
         if (p.ebias) {
-          const float* e = p.ebias + (size_t)(n / p.lout) * p.ebias_ld + p.ebias_off + co;
+          const int bb = n / p.lout;
+          const float* e = eb_staged ? eb_lds + (bb - b_first) * TCH + wc * WCO + c * VEC
+                                     : p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co;
 #pragma unroll
           for (int h = 0; h < VEC / 4; ++h) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
@@ -258,7 +310,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
         for (int j = 0; j < VEC; ++j) v[j] = tdx_act(v[j], p.act);
         if (p.res) {
           float rv[VEC];
-          Elem<T>::unpack(*reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * sizeof(T)), rv);
+          Elem<T>::unpack(resv[ni][i], rv);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) v[j] += rv[j];
         }
@@ -274,8 +326,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   if constexpr (GN) {
     const float inv_cnt = 1.0f / ((float)cpg * (float)p.gn_L);
     __syncthreads();
-    reduce_rows(tab_mean, inv_cnt);
+    if (!(p.debug & 8)) reduce_rows(tab_mean, inv_cnt);
     __syncthreads();
+    if (!(p.debug & 16))
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -292,14 +345,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
         row_partial(d, row_local);
       }
     __syncthreads();
-    reduce_rows(tab_var, inv_cnt);
+    if (!(p.debug & 8)) reduce_rows(tab_var, inv_cnt);
     __syncthreads();
-    float gm[VEC], bt[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      gm[j] = co_ok ? p.gn_gamma[co + j] : 0.f;
-      bt[j] = co_ok ? p.gn_beta[co + j] : 0.f;
-    }
+    if (!(p.debug & 32))
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -777,7 +825,6 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     if (t == 123.456f) p.out[0] = 1;  // keeps the accumulators live without storing the tile
     return;
   }
-  __syncthreads();  // every wave is done reading the stage buffers; reuse them as per-wave transpose patches
   epilogue_lds<T, MI, NI, TC / 2, TC, GN>(p, acc, smem, wave, wr, wc, lane, n0, co0);
 #endif
 }
@@ -788,7 +835,7 @@ constexpr size_t dma_lds_bytes(int tc, bool win) {
 // LDS the GroupNorm epilogue needs: 8 transpose patches + per-row partials + mean/var tables
 inline size_t gn_lds_bytes(int tc, int cpg, int L) {
   const size_t gt = tc / cpg;
-  return 8 * 16 * (size_t)(tc / 2 * 4 + 16) + 256 * gt * 4 + 2 * (size_t)(256 / L + 1) * gt * 4;
+  return 8 * 16 * (size_t)(tc / 2 * 4 + 16) + 256 * gt * 4 + 2 * (size_t)(256 / L + 1) * gt * 4 + (size_t)kEbMaxTraj * tc * 4;
 }
 
 template <typename T, int TC, bool WIN, bool GN>

@@ -70,7 +70,8 @@ struct Elem<__bf16> {
   }
 };
 
-__device__ __forceinline__ float tdx_swish(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 and reciprocal (about 1e-6 relative error; an IEEE divide costs ~5x more VALU)
+__device__ __forceinline__ float tdx_swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tdx_leaky(float x) { return x > 0.f ? x : 0.1f * x; }
 __device__ __forceinline__ float tdx_act(float x, int act) {
   return act == TDX_ACT_SWISH ? tdx_swish(x) : (act == TDX_ACT_LEAKY ? tdx_leaky(x) : x);

@@ -16,6 +16,9 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_SWISH, ConvDesc, TdxError
 
 
+FUSE_GN_DEFAULT = False
+
+
 def conv_out_len(l: int, stride: int) -> int:
     """Conv1d(k=3, p=1, stride) output length (Models/TrajUNet.py:52)."""
     return (l - 1) // stride + 1
@@ -69,6 +72,10 @@ class Program:
         self.flops: Dict[int, float] = {}  # op index -> algorithmic FLOPs (GEMM ops only)
         self.keep: List = []  # tensors / descriptors referenced by raw pointer
         self._pool: Dict[Tuple[int, torch.dtype], List[torch.Tensor]] = {}
+        # Fusing the consumer's GroupNorm into the conv epilogue is implemented and tested, but on MI355X the separate
+        # GroupNorm pass (full-chip HBM stream) beats a longer, un-overlapped epilogue on every TrajUNet shape
+        # (profiles/r1_gn_fusion_ablation.txt), so programs use it only on request.
+        self.fuse_gn = FUSE_GN_DEFAULT
 
     # ---- workspace -------------------------------------------------------------------------
     def alloc(self, shape: Sequence[int], dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -119,7 +126,7 @@ class Program:
         if gn is not None:
             d.gn_gamma, d.gn_beta = gn.gamma.data_ptr() + 4 * gn.p_off, gn.beta.data_ptr() + 4 * gn.p_off
             d.gn_out, d.gn_ld, d.gn_off, d.gn_act, d.gn_cpg, d.gn_eps = gn.out.data_ptr(), gn.out_ld, gn.out_off, gn.act, gn.cpg, gn.eps
-            fused = bool(self.lib.tdx_conv_gemm_gn_fusable(C.byref(d)))
+            fused = self.fuse_gn and bool(self.lib.tdx_conv_gemm_gn_fusable(C.byref(d)))
             if not fused:
                 d.gn_gamma = None
                 if out is None:  # the separate GroupNorm kernel needs the raw tensor

@@ -160,7 +160,7 @@ def test_conv_large_tiles_dma_kernel(dt, case):
     if case == "k1_res":
         kw.update(res=torch.randn(B, Co, L, generator=g), ebias=torch.randn(B, Co + 8, generator=g), act=2)
     got = run_conv(dt, x, w, b, **kw)
-    for bits in (1, 2):  # 1: register-staged 128x128 kernel; 2: LDS-DMA kernel without the shared tap window
+    for bits in (1, 2, 8):  # 1: register-staged 128x128 kernel; 2: LDS-DMA without the shared tap window; 8: no 128-row tiles
         _lib.lib().tdx_conv_gemm_force_small(bits)
         try:
             other = run_conv(dt, x, w, b, **kw)

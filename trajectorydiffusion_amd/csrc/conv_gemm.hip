@@ -55,7 +55,6 @@ int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
 int g_debug = 0;
 constexpr int kRowBytes = 128;  // one K-step of one tile row: 64 bf16 / 32 fp32
 constexpr int kThreads = 256;
-constexpr int kDmaThreadsC = 512;
 constexpr int kEbMaxTraj = 24;  // embed-bias rows staged in LDS per tile (trajectories of >= 11 rows)
 
 // Run f(integral_constant<int, tap>) for a wave-uniform runtime tap in {0, 1, 2}: every per-tap register array is then
@@ -156,12 +155,14 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4 (&acc)[MI][NI]
 // so every (trajectory, group) statistic is complete inside the workgroup.  Statistics are exact two-pass
 // (mean, then centred squares) and bitwise reproducible: per-row partial sums by xor-shuffles -> LDS table ->
 // fixed-order tree over the L rows.  No atomics.
-template <typename T, int MI, int NI, int WCO, int TCH, bool GN>
+template <typename T, int MI, int NI, int WCO, int TCH, int TRW, bool GN>
 __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI][NI], char* smem, int wave, int wr, int wc, int lane,
                                              int n0, int co0) {
   constexpr int VEC = 16 / (int)sizeof(T);      // output elements per 16-byte store
   constexpr int STRIDE = WCO * 4 + 16;          // fp32 patch row, padded: conflict-free ds_write_b128
   constexpr int PATCH = 16 * STRIDE;
+  constexpr int NWV = TRW / 32;                 // waves per workgroup
+  constexpr int NT = NWV * 64;
   constexpr int CPR = WCO / VEC;                // 16-byte output chunks per row
   constexpr int RPP = 64 / CPR;                 // rows per pass
   constexpr int NP = 16 / RPP;
@@ -211,21 +212,21 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   const int LPG = cpg >= VEC ? cpg / VEC : 1;        // lanes that share one group within a row
   const bool two = cpg < VEC;                        // two groups inside one 16-byte vector (cpg == VEC / 2)
   const int g0 = (wc * WCO + c * VEC) / cpg;         // this lane's (first) group inside the block tile
-  float* rs = reinterpret_cast<float*>(smem + 8 * PATCH);   // [256 rows][GT] per-row partial sums
-  float* tab_mean = rs + 256 * GT;                            // [trajectories in tile][GT]
-  float* tab_var = tab_mean + (256 / p.gn_L + 1) * GT;
+  float* rs = reinterpret_cast<float*>(smem + NWV * PATCH);   // [tile rows][GT] per-row partial sums
+  float* tab_mean = rs + TRW * GT;                            // [trajectories in tile][GT]
+  float* tab_var = tab_mean + (TRW / p.gn_L + 1) * GT;
   // [trajectories touched][TCH] staged embed-bias rows
-  float* eb_lds = GN ? tab_var + (256 / p.gn_L + 1) * GT : reinterpret_cast<float*>(smem + 8 * PATCH);
+  float* eb_lds = GN ? tab_var + (TRW / p.gn_L + 1) * GT : reinterpret_cast<float*>(smem + NWV * PATCH);
   const int b_first = n0 / p.lout;
   const int ntraj = (n_end - 1) / p.lout - b_first + 1;
   const bool eb_staged = p.ebias && ntraj <= kEbMaxTraj;
-  constexpr int EBR = (kEbMaxTraj * (TCH / 4) + kDmaThreadsC - 1) / kDmaThreadsC;  // float4 slots per thread
+  constexpr int EBR = (kEbMaxTraj * (TCH / 4) + NT - 1) / NT;  // float4 slots per thread
   f32x4 ebv[EBR];
   const int tid_e = wave * 64 + lane;
   if (eb_staged) {
 #pragma unroll
     for (int k = 0; k < EBR; ++k) {
-      const int idx = tid_e + k * kDmaThreadsC;
+      const int idx = tid_e + k * NT;
       const int t = idx / (TCH / 4), q4 = idx - t * (TCH / 4);
       const int cc = co0 + q4 * 4;
       ebv[k] = (t < ntraj && cc < p.cout) ? *reinterpret_cast<const f32x4*>(p.ebias + (size_t)(b_first + t) * p.ebias_ld + p.ebias_off + cc)
@@ -236,7 +237,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   if (eb_staged) {
 #pragma unroll
     for (int k = 0; k < EBR; ++k) {
-      const int idx = tid_e + k * kDmaThreadsC;
+      const int idx = tid_e + k * NT;
       if (idx < ntraj * (TCH / 4)) *reinterpret_cast<f32x4*>(eb_lds + idx * 4) = ebv[k];
     }
     __syncthreads();
@@ -260,8 +261,8 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
   auto reduce_rows = [&](float* tab, float scale) {
     const int L = p.gn_L, E = (p.tile_rows / L) * GT;
     int tpe = 64;
-    while (tpe > 1 && E * tpe > kDmaThreadsC) tpe >>= 1;
-    const int tid = wave * 64 + lane, sub = tid & (tpe - 1), per_round = kDmaThreadsC / tpe;
+    while (tpe > 1 && E * tpe > NT) tpe >>= 1;
+    const int tid = wave * 64 + lane, sub = tid & (tpe - 1), per_round = NT / tpe;
     for (int e0 = 0; e0 < E; e0 += per_round) {
       const int e = e0 + tid / tpe;
       float sum = 0.f;
@@ -548,10 +549,9 @@ int launch(const ConvArgs& a, hipStream_t st) {
 //   channel block is staged ONCE and serves all three taps: tap t of output row i reads window row i + t, or a
 //   permanently-zero LDS row when l + t - 1 falls outside the trajectory (Conv1d's padding).  Activation
 //   traffic into LDS drops 3x and the window for block j+1 streams in under the three tap steps of block j.
-constexpr int kDmaThreads = 512;
-constexpr int kDmaRows = 256;
-constexpr int kWinGroups = kDmaRows / 8 + 1;             // 8-row DMA groups per window (rows 0..263)
-constexpr int kWinBytes = (kWinGroups * 8 + 1) * kRowBytes;  // + one zero row
+constexpr int kDmaRows = 256;  // largest row tile (bounds the 32-bit in-tile offsets)
+constexpr int win_groups(int tr) { return tr / 8 + 1; }                      // 8-row DMA groups per window (rows 0 .. tr+7)
+constexpr int win_bytes(int tr) { return (win_groups(tr) * 8 + 1) * 128; }   // + one zero row
 constexpr uint32_t kOob = 0x80000000u;
 
 // Buffer resource words {base_lo, base_hi (stride 0), num_records, flags}, forced into SGPRs.
@@ -585,15 +585,18 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const u3
       : "memory");
 }
 
-template <typename T, int TC, bool WIN, bool GN>
-__global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvArgs p) {
+// TR = 256: 8 waves, one workgroup per CU (big GEMMs).  TR = 128: 4 waves and half the LDS, two workgroups per CU, so one
+// workgroup's epilogue (a pure HBM store phase) overlaps the other's K loop: used for the narrow (Cout <= 128) layers.
+template <typename T, int TC, int TR, bool WIN, bool GN>
+__global__ __launch_bounds__(TR * 2) void conv_gemm_dma_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-  constexpr int TR = kDmaRows;
   constexpr int ES = (int)sizeof(T);
+  constexpr int NW = TR / 32;                     // waves: 2 (channels) x TR/64 (rows)
+  constexpr int kWinGroups = win_groups(TR), kWinBytes = win_bytes(TR);
   constexpr int BK = kRowBytes / ES;
-  constexpr int MI = TC / 32, NI = TR / 64;       // wave tile: (TC/2) channels x 64 rows
-  constexpr int GA = TC / 64, GB = TR / 64;       // 8-row DMA groups per wave per stage
-  constexpr int GW = (kWinGroups + 7) / 8;        // window groups per wave (last one partial)
+  constexpr int MI = TC / 32, NI = 4;             // wave tile: (TC/2) channels x 64 rows
+  constexpr int GA = TC / 8 / NW, GB = TR / 8 / NW;  // 8-row DMA groups per wave per stage
+  constexpr int GW = (kWinGroups + NW - 1) / NW;  // window groups per wave (last one partial)
   constexpr int A_BYTES = TC * kRowBytes, B_BYTES = TR * kRowBytes;
   constexpr int A_STAGE = WIN ? A_BYTES : A_BYTES + B_BYTES;  // distance between the two weight stages
   constexpr int W_BASE = 2 * A_BYTES;                          // WIN: the two activation windows follow the weight stages
@@ -619,13 +622,13 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
   const u32x4 rsrc_a = make_srd(p.w + (size_t)co0 * p.ktot * ES, (uint32_t)rows_a * (uint32_t)p.ktot * ES);
   uint32_t voff_a[GA];
 #pragma unroll
-  for (int i = 0; i < GA; ++i) voff_a[i] = (uint32_t)(8 * (wave + 8 * i) + r8) * (uint32_t)(p.ktot * ES) + chunk_off;  // rows >= rows_a fall out of range
+  for (int i = 0; i < GA; ++i) voff_a[i] = (uint32_t)(8 * (wave + NW * i) + r8) * (uint32_t)(p.ktot * ES) + chunk_off;  // rows >= rows_a fall out of range
   uint32_t soff_a = 0;
   auto issue_a = [&](int buf) {
     const uint32_t a = lds_base + buf * A_STAGE + wave * 1024;
     const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
 #pragma unroll
-    for (int i = 0; i < GA; ++i) dma16(a + i * 8192, voff_a[i], rsrc_a, so);
+    for (int i = 0; i < GA; ++i) dma16(a + i * NW * 1024, voff_a[i], rsrc_a, so);
     soff_a += kRowBytes;
   };
 
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
       rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
 #pragma unroll
       for (int i = 0; i < GW; ++i) {
-        const int srow = n0 - pad + 8 * (wave + 8 * i) + r8;  // flat source row of this lane's window row
+        const int srow = n0 - pad + 8 * (wave + NW * i) + r8;  // flat source row of this lane's window row
         voff_w[i] = (srow >= 0 && srow < p.N) ? (uint32_t)((srow - base_row) * s.src_ld) * ES + chunk_off : kOob;
       }
     } else {
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     const int b0 = n0 / p.lout;
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int i_loc = 8 * (wave + 8 * i) + r8;
+      const int i_loc = 8 * (wave + NW * i) + r8;
       const int n = n0 + i_loc;
       const int b = n / p.lout;
       rb_b[i] = (n < p.N && i_loc < p.tile_rows) ? b - b0 : -1;
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     with_tap(ld_tap, [&](auto tc) {
       constexpr int TAP = decltype(tc)::value;
 #pragma unroll
-      for (int i = 0; i < (WIN ? 0 : GB); ++i) dma16(b + i * 8192, voff_b[TAP][i], rsrc_b, so);
+      for (int i = 0; i < (WIN ? 0 : GB); ++i) dma16(b + i * NW * 1024, voff_b[TAP][i], rsrc_b, so);
     });
     if (++ld_tap >= ld_taps) {
       ld_tap = 0;
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
 #pragma unroll
     for (int i = 0; i < (WIN ? GW : 0); ++i)
-      if (wave + 8 * i < kWinGroups) dma16(w + i * 8192, voff_w[i], rsrc_b, so);
+      if (wave + NW * i < kWinGroups) dma16(w + i * NW * 1024, voff_w[i], rsrc_b, so);
     ld_ci += BK;
     if (ld_ci >= ld_cin) {
       ld_ci = 0;
@@ -825,51 +828,52 @@ __global__ __launch_bounds__(kDmaThreads) void conv_gemm_dma_kernel(const ConvAr
     if (t == 123.456f) p.out[0] = 1;  // keeps the accumulators live without storing the tile
     return;
   }
-  epilogue_lds<T, MI, NI, TC / 2, TC, GN>(p, acc, smem, wave, wr, wc, lane, n0, co0);
+  epilogue_lds<T, MI, NI, TC / 2, TC, TR, GN>(p, acc, smem, wave, wr, wc, lane, n0, co0);
 #endif
 }
 
-constexpr size_t dma_lds_bytes(int tc, bool win) {
-  return win ? 2 * (size_t)tc * kRowBytes + 2 * (size_t)kWinBytes : 2 * (size_t)(kDmaRows + tc) * kRowBytes;
+constexpr size_t dma_lds_bytes(int tc, int tr, bool win) {
+  return win ? 2 * (size_t)tc * kRowBytes + 2 * (size_t)win_bytes(tr) : 2 * (size_t)(tr + tc) * kRowBytes;
 }
-// LDS the GroupNorm epilogue needs: 8 transpose patches + per-row partials + mean/var tables
+// LDS the GroupNorm epilogue needs (256-row tiles only): transpose patches + per-row partials + mean/var tables + embed-bias rows
 inline size_t gn_lds_bytes(int tc, int cpg, int L) {
   const size_t gt = tc / cpg;
   return 8 * 16 * (size_t)(tc / 2 * 4 + 16) + 256 * gt * 4 + 2 * (size_t)(256 / L + 1) * gt * 4 + (size_t)kEbMaxTraj * tc * 4;
 }
 
-template <typename T, int TC, bool WIN, bool GN>
+template <typename T, int TC, int TR, bool WIN, bool GN>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
   const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + a.tile_rows - 1) / a.tile_rows;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
-  size_t lds = dma_lds_bytes(TC, WIN);
+  size_t lds = dma_lds_bytes(TC, TR, WIN);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, WIN, GN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, TR, WIN, GN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_dma: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC, WIN, GN>), grid, dim3(kDmaThreads), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<T, TC, TR, WIN, GN>), grid, dim3(TR * 2), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_dma_kernel");
   return TDX_OK;
 }
 
 template <typename T>
-int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, bool win, bool gn) {
-  if (gn) {
-    if (win) return tc == 256 ? launch_dma<T, 256, true, true>(a, st) : launch_dma<T, 128, true, true>(a, st);
-    return tc == 256 ? launch_dma<T, 256, false, true>(a, st) : launch_dma<T, 128, false, true>(a, st);
+int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, bool gn) {
+  if (gn) {  // GroupNorm epilogue: 256-row tiles only
+    if (win) return tc == 256 ? launch_dma<T, 256, 256, true, true>(a, st) : launch_dma<T, 128, 256, true, true>(a, st);
+    return tc == 256 ? launch_dma<T, 256, 256, false, true>(a, st) : launch_dma<T, 128, 256, false, true>(a, st);
   }
-  if (win) return tc == 256 ? launch_dma<T, 256, true, false>(a, st) : launch_dma<T, 128, true, false>(a, st);
-  return tc == 256 ? launch_dma<T, 256, false, false>(a, st) : launch_dma<T, 128, false, false>(a, st);
+  if (tr == 128) return win ? launch_dma<T, 128, 128, true, false>(a, st) : launch_dma<T, 128, 128, false, false>(a, st);
+  if (win) return tc == 256 ? launch_dma<T, 256, 256, true, false>(a, st) : launch_dma<T, 128, 256, true, false>(a, st);
+  return tc == 256 ? launch_dma<T, 256, 256, false, false>(a, st) : launch_dma<T, 128, 256, false, false>(a, st);
 }
 
 }  // namespace
 
 // Validate a descriptor, translate it to kernel arguments and choose the kernel.  kind: 0 = register-staged
 // 128x128, 1 = LDS-DMA gather, 2 = LDS-DMA window; tc = channel tile of the DMA kernels; gn = fused GroupNorm.
-struct Choice { int kind, tc; bool gn; };
+struct Choice { int kind, tc, tr; bool gn; };
 
 static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   TDX_CHECK_ARG(d != nullptr, "tdx_conv_gemm: null descriptor");
@@ -941,7 +945,9 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   dma_ok = dma_ok && d->cout % vec == 0 && (!d->out || (d->out_off % vec == 0 && d->out_ld % vec == 0)) && (!d->res || d->res_ld % vec == 0);
   const int tc = (d->cout % 256 == 0) ? 256 : 128;
   const int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
-  ch = Choice{0, tc, false};
+  // narrow outputs: 128-row tiles, two workgroups per CU (epilogue of one under the K loop of the other)
+  const int tr = (tc == 128 && !(g_force & 8)) ? 128 : 256;
+  ch = Choice{0, tc, tr, false};
   if (want_gn) {
     TDX_CHECK_ARG(d->gn_beta && d->gn_out, "tdx_conv_gemm: fused GroupNorm needs gn_beta and gn_out");
     TDX_CHECK_ARG(d->gn_act >= TDX_ACT_NONE && d->gn_act <= TDX_ACT_SWISH, "tdx_conv_gemm: bad gn_act %d", d->gn_act);
@@ -949,7 +955,7 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
     const int cpg = d->gn_cpg;
     bool ok = dma_ok && !(g_force & 4) && d->lout <= kDmaRows && cpg >= 4 && cpg >= vec / 2 && (cpg & (cpg - 1)) == 0 && cpg <= tc / 2 &&
               d->gn_off % vec == 0 && d->gn_ld % vec == 0 && d->gn_off + d->cout <= d->gn_ld;
-    ok = ok && gn_lds_bytes(tc, cpg, d->lout) <= dma_lds_bytes(tc, win_ok);
+    ok = ok && gn_lds_bytes(tc, cpg, d->lout) <= dma_lds_bytes(tc, 256, win_ok);
     if (!ok) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_conv_gemm: this shape cannot fuse the GroupNorm (lout=%d cout=%d cpg=%d): run tdx_groupnorm_act", d->lout, d->cout, cpg);
     a.tile_rows = (kDmaRows / d->lout) * d->lout;
     a.gn_gamma = d->gn_gamma;
@@ -960,9 +966,10 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
     a.gn_act = d->gn_act;
     a.gn_cpg = cpg;
     a.gn_eps = d->gn_eps;
-    ch = Choice{win_ok ? 2 : 1, tc, true};
+    ch = Choice{win_ok ? 2 : 1, tc, 256, true};
   } else if (dma_ok && tiles >= 128) {
-    ch = Choice{win_ok ? 2 : 1, tc, false};
+    ch = Choice{win_ok ? 2 : 1, tc, tr, false};
+    a.tile_rows = tr;
   }
   return TDX_OK;
 }
@@ -980,15 +987,16 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   if (rc != TDX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (ch.kind != 0) {
-    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, ch.tc, ch.kind == 2, ch.gn);
-    return dispatch_dma<__bf16>(a, st, ch.tc, ch.kind == 2, ch.gn);
+    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, ch.tc, ch.tr, ch.kind == 2, ch.gn);
+    return dispatch_dma<__bf16>(a, st, ch.tc, ch.tr, ch.kind == 2, ch.gn);
   }
   if (d->dtype == TDX_F32) return launch<float, 128, 128>(a, st);
   return launch<__bf16, 128, 128>(a, st);
 }
 
 // Test hooks (not part of the reference-facing surface).
-// force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable.
+// force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable,
+//             8 = never use the 128-row (two workgroups per CU) tiles.
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   g_force = bits;
   return TDX_OK;

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--L", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     a = ap.parse_args()
 
@@ -87,7 +89,10 @@ def main():
     gathered = torch.empty((world * B, 2, L), device=dev) if world > 1 else None
 
     def one_step():
-        x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
+        if a.sampler == "ddim":
+            x0 = dm.ddimBackward(x_T, cat, num, model, n_steps=a.ddim_steps, use_graph=not a.no_graph)
+        else:
+            x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
         if world > 1:
             dist.all_gather_into_tensor(gathered, x0)
         return x0
@@ -114,6 +119,7 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / elapsed
+        n_denoise = a.ddim_steps if a.sampler == "ddim" else a.T
         # roofline of the dominant kernel (conv_gemm): per-launch HIP-event times of one denoise step
         prog = model.program(B, L, dev, split_embed=True)
         prof = prog.pg.profile(repeats=3)
@@ -121,17 +127,27 @@ def main():
         gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
         step_ms = sum(ms for _, _, ms, _ in prof)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), stored per round
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if pm["workload"] == f"B={B}, L={L}, {a.dtype}":
+                traffic = round(pm["conv_gemm_bytes_per_launch_avg"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
-            "metric": "trajectories/sec, TrajUNet 500-step DDPM sampling L=200", "value": round(value, 3), "unit": "trajectories/s",
+            "metric": "trajectories/sec, TrajUNet 500-step DDPM sampling L=200" if a.sampler == "ddpm" and a.T == 500 else f"trajectories/sec, TrajUNet {a.sampler} sampling ({n_denoise} denoise steps) L={L}", "value": round(value, 3), "unit": "trajectories/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"C2: TrajUNet DDPM {a.T}-step sampling, B={B} per GPU, L={L}, schedule {SCHEDULE}, random-init weights",
+            "config": {"workload": (f"C2: TrajUNet DDPM {a.T}-step sampling" if a.sampler == "ddpm" else f"C3: TrajUNet DDIM {a.ddim_steps}-step sampling (T={a.T} table)")
+                       + f", B={B} per GPU, L={L}, schedule {SCHEDULE}, random-init weights",
                        "batch_per_gpu": B, "global_batch": world * B, "diffusion_steps": a.T, "parallelism": f"batch-shard x{world}"},
-            "ms_per_denoise_step": round(1e3 * elapsed / a.steps / a.T, 4),
-            "model_tflops": round(value * a.T * FLOP_PER_TRAJ_STEP / 1e12 / world, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all %d launches of one denoise step)" % len(gemm),
+            "ms_per_denoise_step": round(1e3 * elapsed / a.steps / n_denoise, 4),
+            "model_tflops": round(value * n_denoise * FLOP_PER_TRAJ_STEP / 1e12 / world, 2),
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel, tdx_conv_gemm (all %d launches of one denoise step)" % len(gemm),
                          "achieved": round(achieved, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.dtype], 4),
-                         "traffic": None, "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
+                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, bytes per launch, avg of 38)",
+                         "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * 2 * B / 38) if a.dtype == "bf16" else None, "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
                          "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms, 3),
                          "all_kernels_ms_per_step": round(step_ms, 3)},
         }

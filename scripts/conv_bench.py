@@ -14,6 +14,7 @@ from trajectorydiffusion_amd import _lib, engine  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--debug", type=int, nargs="*", default=[0])
 ap.add_argument("--small", action="store_true")
+ap.add_argument("--force", type=int, nargs="*", default=None, help="tdx_conv_gemm_force_small settings to compare (one column each)")
 ap.add_argument("--gn", action="store_true", help="fuse a consumer GroupNorm+Swish into the epilogue")
 ap.add_argument("--noraw", action="store_true")
 ap.add_argument("--gnact", type=int, default=2)
@@ -28,8 +29,8 @@ SHAPES = [  # (name, L, Cin, Cout, taps)
     ("qkv 1024->3072@13", 13, 1024, 3072, 1),
 ]
 lib = _lib.lib()
-lib.tdx_conv_gemm_force_small(1 if a.small else 0)
-print(f"{'shape':22s} " + " ".join(f"dbg{d}: ms / TF  " for d in a.debug))
+forces = a.force if a.force is not None else [1 if a.small else 0]
+print(f"{'shape':22s} " + " ".join(f"f{f}/dbg{d}: ms / TF  " for f in forces for d in a.debug))
 for name, L, ci, co, k in SHAPES:
     x = torch.randn((B, L, ci), device="cuda").to(dt)
     w = (torch.randn((co, k * ci), device="cuda") / (k * ci) ** 0.5).to(dt)
@@ -47,7 +48,8 @@ for name, L, ci, co, k in SHAPES:
         continue
     fl = 2.0 * B * L * co * k * ci
     cells = []
-    for d in a.debug:
+    for f, d in [(f, d) for f in forces for d in a.debug]:
+        lib.tdx_conv_gemm_force_small(f)
         lib.tdx_conv_gemm_debug(d)
         for _ in range(3):
             pg.run()
@@ -61,4 +63,5 @@ for name, L, ci, co, k in SHAPES:
         ms = e0.elapsed_time(e1) / 10
         cells.append(f"{ms:7.3f} / {fl / ms / 1e9:6.0f}")
     lib.tdx_conv_gemm_debug(0)
+    lib.tdx_conv_gemm_force_small(0)
     print(f"{name:22s} " + "   ".join(cells))

@@ -133,10 +133,12 @@ def test_conv_concat_plus_shortcut_segments(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("case", ["s1_c128", "s1_c256", "s2", "up", "k1_res", "tail_rows"])
+@pytest.mark.parametrize("case", ["s1_c128", "s1_c256", "s2", "up", "k1_res", "tail_rows", "stream_win", "stream_s2", "stream_up", "stream_c128"])
 def test_conv_large_tiles_dma_kernel(dt, case):
-    """Shapes big enough for the 256-row LDS-DMA kernels (window and gather variants): checked against F.conv1d AND
-    bit-for-bit against each other and the 128x128 register-staged kernel (same K order, same MFMA chain)."""
+    """Shapes big enough for the LDS-DMA kernels (window and gather variants, persistent and one-tile-per-workgroup forms,
+    with and without the small-tile tail launch): checked against F.conv1d AND bit-for-bit against each other and the
+    128x128 register-staged kernel (same K order, same MFMA chain).  The stream_* cases give every workgroup of the
+    persistent kernel two or more tiles plus a partial last round (569 tiles of 256 rows on 256 CUs)."""
     engine, _lib = _eng()
     g = torch.Generator().manual_seed(len(case))
     kw = {}
@@ -152,15 +154,30 @@ def test_conv_large_tiles_dma_kernel(dt, case):
         kw["upmap_to"] = 25
     elif case == "k1_res":
         B, L, Ci, Co, k = 2600, 13, 256, 768, 1
+    elif case == "stream_win":
+        B, L, Ci, Co, k = 1457, 100, 128, 256, 3
+    elif case == "stream_s2":
+        B, L, Ci, Co, k = 1457, 200, 128, 256, 3
+        kw["stride"] = 2
+    elif case == "stream_up":
+        B, L, Ci, Co, k = 2914, 25, 128, 256, 3
+        kw["upmap_to"] = 50
+    elif case == "stream_c128":
+        B, L, Ci, Co, k = 1300, 200, 128, 128, 3   # 2032 tiles of 128 rows on 512 workgroup slots
     else:
         B, L, Ci, Co, k = 331, 101, 64, 384, 3   # N = 33431: ragged last row tile; Co = 384 -> 128-wide channel tiles
     x = torch.randn(B, Ci, L, generator=g)
     w = torch.randn(Co, Ci, k, generator=g) / (k * Ci) ** 0.5
     b = torch.randn(Co, generator=g)
-    if case == "k1_res":
-        kw.update(res=torch.randn(B, Co, L, generator=g), ebias=torch.randn(B, Co + 8, generator=g), act=2)
+    lo = kw.get("upmap_to", (L - 1) // kw.get("stride", 1) + 1)
+    if case in ("k1_res", "stream_win", "stream_s2", "stream_c128"):
+        kw.update(res=torch.randn(B, Co, lo, generator=g), ebias=torch.randn(B, Co + 8, generator=g), act=2)
+    if case in ("stream_win", "stream_up"):
+        kw.update(tbias=torch.randn(Co + 8, generator=g))
     got = run_conv(dt, x, w, b, **kw)
-    for bits in (1, 2, 8):  # 1: register-staged 128x128 kernel; 2: LDS-DMA without the shared tap window; 8: no 128-row tiles
+    # 1: register-staged 128x128 kernel; 2: LDS-DMA without the shared tap window; 8: no 128-row tiles; 16: no tail launch;
+    # 32: one tile per workgroup instead of the persistent kernel
+    for bits in (1, 2, 8, 16, 32, 48, 34, 64, 80):
         _lib.lib().tdx_conv_gemm_force_small(bits)
         try:
             other = run_conv(dt, x, w, b, **kw)
@@ -171,7 +188,9 @@ def test_conv_large_tiles_dma_kernel(dt, case):
     if "upmap_to" in kw:
         xq = F.interpolate(xq, size=kw["upmap_to"], mode="nearest")
     ref = F.conv1d(xq, q(w, dt), b, stride=kw.get("stride", 1), padding=k // 2)
-    if case == "k1_res":
+    if "tbias" in kw:
+        ref = ref + kw["tbias"][None, 8:, None]
+    if "ebias" in kw:
         ref = swish(ref + kw["ebias"][:, 8:, None]) + q(kw["res"], dt)
     assert rel(got, ref) < TOL[dt]
 

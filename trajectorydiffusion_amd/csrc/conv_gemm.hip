@@ -43,6 +43,9 @@ struct ConvArgs {
   int32_t out_ld, out_off;
   int32_t N, lout, cout, B;
   int32_t tile_rows;  // rows per row tile of the DMA kernels: 256, or k * L when the GroupNorm epilogue needs whole trajectories
+  int32_t n_begin, row_tiles;  // DMA kernels: this launch covers row tiles [0, row_tiles) counted from output row n_begin
+  uint64_t div_m;              // n / lout == (n * div_m) >> div_k for 0 <= n < 2^31 (stream kernel: no integer divides per tile)
+  int32_t div_k;
   const float* gn_gamma;
   const float* gn_beta;
   char* gn_out;
@@ -52,6 +55,7 @@ struct ConvArgs {
 };
 
 int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
+int g_tail_max = 128;  // largest remainder (in 256-row tiles) handed to the small-tile tail launch
 int g_debug = 0;
 constexpr int kRowBytes = 128;  // one K-step of one tile row: 64 bf16 / 32 fp32
 constexpr int kThreads = 256;
@@ -102,18 +106,22 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4 (&acc)[MI][NI]
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j];
+      // same association as the LDS-DMA epilogues: acc + (bias + time-step row) + per-trajectory row
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += t[j];
-      }
-      if (p.ebias) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)b * p.ebias_ld + p.ebias_off + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += t[j];
+        for (int j = 0; j < 4; ++j) bs[j] += t[j];
       }
       if (p.tbias) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p.tbias + p.ebias_off + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[j] += t[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += bs[j];
+      if (p.ebias) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)b * p.ebias_ld + p.ebias_off + co);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += t[j];
       }
@@ -298,13 +306,22 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& p, f32x4 (&acc)[MI]
         for (int j = 0; j < VEC; ++j) v[j] += bs[j];
         if (p.ebias) {
           const int bb = n / p.lout;
-          const float* e = eb_staged ? eb_lds + (bb - b_first) * TCH + wc * WCO + c * VEC
-                                     : p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co;
+          if (eb_staged) {  // (two separate branches: a pointer select would become flat loads, which wait for vmcnt(0))
+            const float* e = eb_lds + (bb - b_first) * TCH + wc * WCO + c * VEC;
 #pragma unroll
-          for (int h = 0; h < VEC / 4; ++h) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
+            for (int h = 0; h < VEC / 4; ++h) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+              for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+            }
+          } else {
+            const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co;
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+            }
           }
         }
 #pragma unroll
@@ -610,8 +627,8 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_dma_kernel(const ConvArgs p)
   const int nco = (p.cout + TC - 1) / TC;
   const int xcd = blockIdx.x & 7, jt = blockIdx.x >> 3;
   const int row_tile = (jt / nco) * 8 + xcd;
-  const int n0 = row_tile * p.tile_rows;
-  if (n0 >= p.N) return;
+  const int n0 = p.n_begin + row_tile * p.tile_rows;
+  if (row_tile >= p.row_tiles || n0 >= p.N) return;
   const int co0 = (jt % nco) * TC;
   const int fr = lane & 15, fq = lane >> 4;
 
@@ -832,6 +849,502 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_dma_kernel(const ConvArgs p)
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Streaming (persistent) form of the LDS-DMA kernel: one workgroup per CU slot walks a list of tiles, and the
+// K-steps of all its tiles form ONE software pipeline.  At the end of a tile the loader moves on first: the
+// next tile's first weight stage and activation window are requested BEFORE the epilogue runs, the epilogue
+// transposes through the two buffers the last K-step has just released (nothing is reserved for it), and its
+// global stores are issued from asm and never waited for: the first K-step of the next tile waits with a
+// counted vmcnt that covers the DMAs (older) but not the stores (younger).  So the tile prologue (DMA latency),
+// the store drain and the workgroup launch all disappear under MFMA work instead of recurring per tile.
+__device__ __forceinline__ int fdiv(int n, uint64_t m, int k) { return (int)(((uint64_t)(uint32_t)n * m) >> k); }
+
+// 16-byte store through a buffer descriptor; lanes with an out-of-range offset are dropped by the hardware, so the
+// instruction is issued by every wave exactly once per call (the counted wait above depends on that).
+__device__ __forceinline__ void buf_store16(const u32x4& v, uint32_t voff, const u32x4& srd) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd) : "memory");
+}
+
+template <typename T, int TC, int TR>
+struct StreamCfg {
+  static constexpr int NW = TR / 32;
+  static constexpr int PATCH = 16 * (64 * 4 + 16);             // one wave's transpose patch: 16 rows x 64 fp32 channels, padded
+  static constexpr int WU = win_groups(TR) * 8 * kRowBytes;    // window bytes below its zero row
+  static constexpr int NPW = WU / PATCH < NW ? WU / PATCH : NW;  // window mode: patches that fit the released window
+  static constexpr int EBT = TR == 256 ? 22 : 12;              // embed-bias rows staged per tile (trajectories touched)
+  static constexpr int NST = 4 * (TC / 2 / 64) * (16 / (64 / (64 / (16 / (int)sizeof(T)))));  // stores per wave per tile
+  static_assert((NW - NPW) * PATCH + EBT * TC * 4 <= TC * kRowBytes, "window-mode epilogue scratch does not fit the released weight stage");
+  static_assert(NW * PATCH + EBT * TC * 4 <= (TC + TR) * kRowBytes, "gather-mode epilogue scratch does not fit the released stage");
+};
+
+// Epilogue of the stream kernel, in two parts.
+//   epi_prefetch: every global READ of the epilogue (bias, per-step embed row, the tile's per-trajectory embed rows and,
+//     for 128-channel tiles, the residual vectors) is issued at the top of the tile's LAST K-step, into registers, and
+//     epi_pin makes the compiler wait for them right after that step's MFMAs, i.e. BEFORE the next tile's DMAs are
+//     issued.  vmcnt counts in issue order, so a read issued after those DMAs would wait for them too.
+//   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
+//     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
+//     residual of 256-channel tiles (no registers to hold it during the K loop).
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES>
+struct Epi {
+  static constexpr bool PRE = PRE_RES;  // 256-channel tiles: no register room in the K loop, everything is read in finish()
+  static constexpr int ES = (int)sizeof(T);
+  static constexpr int VEC = 16 / ES;
+  static constexpr int PC = 64, NH = WCO / PC;  // channels per transpose pass, passes per sub-tile row
+  static constexpr int STRIDE = PC * 4 + 16;
+  static constexpr int CPR = PC / VEC, RPP = 64 / CPR, NP = 16 / RPP;
+  static constexpr int NT = NWV * 64;
+  static constexpr int EBR = (EBT * (TCH / 4) + NT - 1) / NT;
+  static constexpr int NST = NI * NH * NP;      // store instructions per wave per tile
+  float bs[NH][VEC];
+  f32x4 ebv[EBR];
+  u32x4 resv[NI][NH][NP];
+  int b_first, ntraj, n_end;
+  bool eb_staged;
+
+  // The lane index is passed through an opaque asm in each part, so that none of the lane-dependent offsets below is
+  // loop-invariant for the compiler: hoisted out of the tile loop they would sit in VGPRs across the K loop, whose
+  // register budget (128 accumulators + fragments) has no room for them (a spill reload there is a vector-memory
+  // operation, and waiting for it waits for every DMA in flight).
+  static __device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
+
+  __device__ __forceinline__ void load_res(const ConvArgs& p, int wr, int wc, int lane, int n0, int co0) {
+    const int c = lane % CPR, r0 = lane / CPR;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
+          const int co = co0 + wc * WCO + h * PC + c * VEC;
+          resv[ni][h][i] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES)
+                                                      : (u32x4){0u, 0u, 0u, 0u};
+        }
+  }
+
+  __device__ __forceinline__ void prefetch(const ConvArgs& p, int wave, int wr, int wc, int lane_, int n0, int co0) {
+    const int lane = opaque(lane_);
+    const int c = lane % CPR;
+    n_end = n0 + p.tile_rows < p.N ? n0 + p.tile_rows : p.N;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int co = co0 + wc * WCO + h * PC + c * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) bs[h][j] = 0.f;
+      if (co < p.cout) {
+        if (p.bias)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) bs[h][j] += p.bias[co + j];
+        if (p.tbias)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) bs[h][j] += p.tbias[p.ebias_off + co + j];
+      }
+    }
+    b_first = fdiv(n0, p.div_m, p.div_k);
+    ntraj = fdiv(n_end - 1, p.div_m, p.div_k) - b_first + 1;
+    eb_staged = p.ebias && ntraj <= EBT;
+    if (eb_staged) {
+      const int tid_e = wave * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < EBR; ++k) {
+        const int idx = tid_e + k * NT;
+        const int t = idx / (TCH / 4), q4 = idx - t * (TCH / 4);
+        const int cc = co0 + q4 * 4;
+        ebv[k] = (t < ntraj && cc < p.cout) ? *reinterpret_cast<const f32x4*>(p.ebias + (size_t)(b_first + t) * p.ebias_ld + p.ebias_off + cc)
+                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (PRE_RES && p.res) load_res(p, wr, wc, lane, n0, co0);
+  }
+
+  // Consume every prefetched register in an (empty) asm statement: the compiler's wait for the loads lands here.
+  __device__ __forceinline__ void pin(const ConvArgs& p) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) asm volatile("" : "+v"(bs[h][j]));
+    if (eb_staged)
+#pragma unroll
+      for (int k = 0; k < EBR; ++k) asm volatile("" : "+v"(ebv[k]));
+    if (PRE_RES && p.res)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(resv[ni][h][i]));
+  }
+
+  template <int MI>
+  __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], char* patch, float* eb_lds, int wave, int wr, int wc,
+                                         int lane_, int n0, int co0) {
+    const int lane = opaque(lane_);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int c = lane % CPR, r0 = lane / CPR;
+    const int cw = co0 + wc * WCO;  // first channel of this wave's tile
+    if constexpr (!PRE) prefetch(p, wave, wr, wc, lane, n0, co0);
+    if (!PRE_RES && p.res) load_res(p, wr, wc, lane, n0, co0);
+    // output descriptor: base = first element of this wave's tile, range = rest of the output matrix
+    const size_t obase = ((size_t)n0 * p.out_ld + p.out_off + cw) * ES;
+    const size_t oleft = (size_t)p.N * p.out_ld * ES - obase;
+    const u32x4 rsrc_o = make_srd(p.out + obase, oleft > 0x7fffffffull ? 0x7fffffffu : (uint32_t)oleft);
+    __syncthreads();  // every wave is done with the K loop's last buffers: they are epilogue scratch now
+    if (eb_staged) {
+      const int tid_e = wave * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < EBR; ++k) {
+        const int idx = tid_e + k * NT;
+        if (idx < ntraj * (TCH / 4)) *reinterpret_cast<f32x4*>(eb_lds + idx * 4) = ebv[k];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int m = 0; m < PC / 16; ++m)
+          *reinterpret_cast<f32x4*>(patch + fr * STRIDE + (m * 16 + fq * 4) * 4) = acc[h * (PC / 16) + m][ni];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int row = r0 + RPP * i;
+          const int row_local = wr * 64 + ni * 16 + row;
+          const int n = n0 + row_local;
+          float v[VEC];
+#pragma unroll
+          for (int q = 0; q < VEC / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * STRIDE + (c * VEC + q * 4) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[q * 4 + j] = t[j];
+          }
+          const bool live = n < n_end && cw + h * PC + c * VEC < p.cout;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += bs[h][j];
+          if (p.ebias && live) {
+            const int bb = fdiv(n, p.div_m, p.div_k);
+            if (eb_staged) {  // (two separate branches: a pointer select would become flat loads, which wait for vmcnt(0))
+              const float* e = eb_lds + (bb - b_first) * TCH + wc * WCO + h * PC + c * VEC;
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(e + q * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[q * 4 + j] += t[j];
+              }
+            } else {
+              const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + cw + h * PC + c * VEC;
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(e + q * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[q * 4 + j] += t[j];
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = tdx_act(v[j], p.act);
+          if (p.res) {
+            float rv[VEC];
+            Elem<T>::unpack(resv[ni][h][i], rv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] += rv[j];
+          }
+          const uint32_t voff = live ? (uint32_t)(row_local * p.out_ld + h * PC + c * VEC) * ES : kOob;
+          buf_store16(Elem<T>::pack(v), voff, rsrc_o);
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int TC, int TR, bool WIN>
+__global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using Cfg = StreamCfg<T, TC, TR>;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int NW = TR / 32;
+  constexpr int kWinGroups = win_groups(TR), kWinBytes = win_bytes(TR);
+  constexpr int BK = kRowBytes / ES;
+  constexpr int MI = TC / 32, NI = 4;
+  constexpr int GA = TC / 8 / NW, GB = TR / 8 / NW;
+  constexpr int GW = (kWinGroups + NW - 1) / NW;
+  constexpr int A_BYTES = TC * kRowBytes, B_BYTES = TR * kRowBytes;
+  constexpr int A_STAGE = WIN ? A_BYTES : A_BYTES + B_BYTES;
+  constexpr int W_BASE = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int r8 = lane >> 3;
+  const uint32_t chunk_off = (uint32_t)(((lane & 7) ^ r8) << 4);
+
+  // ---- tile list of this workgroup: XCD x = blockIdx & 7 owns row tiles x, x + 8, ...; its workgroups walk
+  //      (row tile, channel tile) pairs in the same order as the one-tile-per-workgroup kernel -----------------------
+  const int nco = (p.cout + TC - 1) / TC;
+  const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+  const int jt_end = nco * ((p.row_tiles + 7) >> 3);
+  auto tile_of = [&](int jt, int& n0, int& co0) -> bool {
+    const int rg = jt / nco, row_tile = rg * 8 + xcd;
+    n0 = p.n_begin + row_tile * p.tile_rows;
+    co0 = (jt - rg * nco) * TC;
+    return jt < jt_end && row_tile < p.row_tiles && n0 < p.N;
+  };
+  int jt = blockIdx.x >> 3, cp_n0, cp_co0;
+  if (!tile_of(jt, cp_n0, cp_co0)) return;
+
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128>;
+  // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
+  int ld_n0 = 0;
+  u32x4 rsrc_a, rsrc_b;
+  // per-lane DMA offsets are kept as ONE base VGPR plus a wave-uniform stride per 8-row group (registers are the
+  // scarce resource of this kernel): rows past the end of a buffer fall out of the descriptor's range by themselves
+  const uint32_t voff_a0 = (uint32_t)(8 * wave + r8) * (uint32_t)(p.ktot * ES) + chunk_off;
+  const uint32_t stride_a = (uint32_t)(8 * NW) * (uint32_t)(p.ktot * ES);
+  uint32_t soff_a = 0;
+  int ld_seg = 0, ld_ci = 0, ld_tap = 0, ld_taps = 1, ld_cin = 0;
+  uint32_t voff_b[3][WIN ? 1 : GB];
+  int rb_b[WIN ? 1 : GB], rb_l[WIN ? 1 : GB];
+  uint32_t voff_w0 = 0, stride_w = 0;
+
+  auto issue_a = [&](int buf) {
+    const uint32_t a = lds_base + buf * A_STAGE + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
+#pragma unroll
+    for (int i = 0; i < GA; ++i) dma16(a + i * NW * 1024, voff_a0 + i * stride_a, rsrc_a, so);
+    soff_a += kRowBytes;
+  };
+  auto ld_setup = [&]() {  // per segment
+    const SegDev& s = p.seg[ld_seg];
+    ld_taps = s.taps;
+    ld_cin = s.cin;
+    const int pad = s.taps == 3 ? 1 : 0;
+    if constexpr (WIN) {
+      const int base_row = ld_n0 - pad > 0 ? ld_n0 - pad : 0;
+      const size_t base = ((size_t)base_row * s.src_ld + s.ch_off) * ES;
+      const size_t left = (size_t)p.N * s.src_ld * ES - base;
+      rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
+      // window row j of the tile = source row n0 - pad + j; row -1 (first tile) wraps to a huge offset, rows >= N lie
+      // beyond num_records: both are out of range for the DMA, which then writes zeros
+      voff_w0 = (uint32_t)((ld_n0 - pad - base_row + 8 * wave + EpiT::opaque(r8)) * s.src_ld * ES) + chunk_off;
+      stride_w = (uint32_t)(8 * NW * s.src_ld * ES);
+    } else {
+      const int b0 = fdiv(ld_n0, p.div_m, p.div_k);
+      const size_t base = ((size_t)b0 * s.lin * s.src_ld + s.ch_off) * ES;
+      const size_t left = (size_t)p.B * s.lin * s.src_ld * ES - base;
+      rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const int u = rb_l[i] * s.stride + t - pad;
+          const bool ok = t < s.taps && rb_b[i] >= 0 && u >= 0 && u < s.lvirt;
+          const int uu = ok ? u : 0;
+          const int srow = s.up_scale > 0.f ? min((int)floorf((float)uu * s.up_scale), s.lin - 1) : uu;
+          voff_b[t][i] = ok ? (uint32_t)((rb_b[i] * s.lin + srow) * s.src_ld) * ES + chunk_off : kOob;
+        }
+    }
+  };
+  auto loader_begin = [&](int n0, int co0) {  // per tile
+    ld_n0 = n0;
+    const int rows_a = p.cout - co0 < TC ? p.cout - co0 : TC;
+    rsrc_a = make_srd(p.w + (size_t)co0 * p.ktot * ES, (uint32_t)rows_a * (uint32_t)p.ktot * ES);
+    soff_a = 0;
+    ld_seg = ld_ci = ld_tap = 0;
+    if constexpr (!WIN) {
+      const int b0 = fdiv(n0, p.div_m, p.div_k);
+      const int r8_o = EpiT::opaque(r8);
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const int i_loc = 8 * (wave + NW * i) + r8_o;
+        const int n = n0 + i_loc;
+        const int b = fdiv(n, p.div_m, p.div_k);
+        rb_b[i] = (n < p.N && i_loc < p.tile_rows) ? b - b0 : -1;
+        rb_l[i] = n - b * p.lout;
+      }
+    }
+    ld_setup();
+  };
+  auto issue_b_gather = [&](int buf) {
+    const uint32_t b = lds_base + buf * A_STAGE + A_BYTES + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
+    with_tap(ld_tap, [&](auto tc) {
+      constexpr int TAP = decltype(tc)::value;
+#pragma unroll
+      for (int i = 0; i < (WIN ? 0 : GB); ++i) dma16(b + i * NW * 1024, voff_b[TAP][i], rsrc_b, so);
+    });
+    if (++ld_tap >= ld_taps) {
+      ld_tap = 0;
+      ld_ci += BK;
+      if (ld_ci >= ld_cin) {
+        ld_ci = 0;
+        ++ld_seg;
+        if (ld_seg < p.nseg) ld_setup();
+      }
+    }
+  };
+  auto issue_window = [&](int wbuf) {
+    const uint32_t w = lds_base + W_BASE + wbuf * kWinBytes + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
+#pragma unroll
+    for (int i = 0; i < (WIN ? GW : 0); ++i)
+      if (wave + NW * i < kWinGroups) dma16(w + i * NW * 1024, voff_w0 + i * stride_w, rsrc_b, so);
+    ld_ci += BK;
+    if (ld_ci >= ld_cin) {
+      ld_ci = 0;
+      ++ld_seg;
+      if (ld_seg < p.nseg) ld_setup();
+    }
+  };
+
+  // ---- MFMA state -------------------------------------------------------------------------------------------------
+  const int a_frag = (wc * (TC / 2) + fr) * kRowBytes;
+  const int sw = fr & 7;
+  f32x4 acc[MI][NI];
+  int cp_seg = 0, cp_ci = 0, cp_tap = 0, cp_taps = 1, cp_cin = 0;
+  uint32_t wmask = 0;
+  int wl[WIN ? NI : 1];
+  auto cp_setup = [&]() {
+    const SegDev& s = p.seg[cp_seg];
+    cp_taps = s.taps;
+    cp_cin = s.cin;
+    wmask = 0;
+#pragma unroll
+    for (int ni = 0; ni < (WIN ? NI : 0); ++ni)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int u = s.taps == 3 ? wl[ni] + t - 1 : wl[ni];
+        const bool ok = t < s.taps && wl[ni] >= 0 && u >= 0 && u < p.lout;
+        wmask |= (ok ? 1u : 0u) << (ni * 3 + t);
+      }
+  };
+  auto compute_begin = [&](int n0) {  // per tile
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    cp_seg = cp_ci = cp_tap = 0;
+    if constexpr (WIN) {
+      const int fr_o = EpiT::opaque(fr);  // (keeps the per-tile index math out of the registers that live across the K loop)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int i_loc = wr * 64 + ni * 16 + fr_o;
+        const int n = n0 + i_loc;
+        wl[ni] = (n < p.N && i_loc < p.tile_rows) ? n - fdiv(n, p.div_m, p.div_k) * p.lout : -1;
+      }
+    }
+    cp_setup();
+  };
+  auto compute = [&](int abuf, int wbuf) {
+    const char* a = smem + abuf * A_STAGE;
+    const char* b = WIN ? smem + W_BASE + wbuf * kWinBytes : a + A_BYTES;
+    int boff[NI];
+    const int shift = WIN ? (cp_taps == 3 ? cp_tap : 0) : 0;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int wrow = wr * 64 + ni * 16 + fr + shift;
+      boff[ni] = wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4);
+      if constexpr (WIN) boff[ni] = ((wmask >> (ni * 3 + cp_tap)) & 1u) ? boff[ni] : kWinGroups * 8 * kRowBytes;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = (((kk << 2) + fq) ^ sw) << 4;
+      u32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(b + (boff[ni] ^ (kk << 6)));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(a + a_frag + mi * 16 * kRowBytes + ch);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[mi], bf[ni], acc[mi][ni]);
+    }
+  };
+
+  if constexpr (WIN) {
+    if (tid < 16)  // the two zero rows (never touched by the DMA, nor by the epilogue scratch)
+      *reinterpret_cast<u32x4*>(smem + W_BASE + (tid >> 3) * kWinBytes + kWinGroups * 8 * kRowBytes + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+
+  // ---- the pipeline: g counts K-steps over all tiles (weight stage g & 1), blk counts channel blocks (window blk & 1) ----
+  static_assert(EpiT::NST == Cfg::NST, "store count must match StreamCfg::NST");
+  EpiT epi;
+  int g = 0, blk = 0;
+  bool counted = false;  // the previous tile's epilogue stores are this wave's youngest vector-memory operations
+  loader_begin(cp_n0, cp_co0);
+  if constexpr (WIN) issue_window(0);
+  issue_a(0);
+  if constexpr (!WIN) issue_b_gather(0);
+  auto step = [&](auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value != 0;
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    counted = false;
+    __syncthreads();
+    if constexpr (!LAST) {
+      issue_a((g + 1) & 1);
+      if constexpr (!WIN) issue_b_gather((g + 1) & 1);
+    }
+    if constexpr (WIN) {
+      if (cp_tap == 0 && ld_seg < p.nseg) issue_window((blk + 1) & 1);
+    }
+    if constexpr (LAST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
+    compute(g & 1, blk & 1);
+    ++g;
+    if (++cp_tap >= cp_taps) {
+      cp_tap = 0;
+      ++blk;
+      cp_ci += BK;
+      if (cp_ci >= cp_cin) {
+        cp_ci = 0;
+        ++cp_seg;
+        if (cp_seg < p.nseg) cp_setup();
+      }
+    }
+  };
+  for (;;) {
+    compute_begin(cp_n0);
+    for (int s = 0; s + 1 < p.nsteps; ++s) step(TapC<0>{});
+    step(TapC<1>{});
+    if constexpr (EpiT::PRE) epi.pin(p);
+    // tile boundary: the loader goes ahead, then the epilogue runs in the buffers the last K-step released
+    int nx_n0, nx_co0;
+    const int jn = jt + nslot;
+    const bool more = tile_of(jn, nx_n0, nx_co0);
+    if (more) {
+      loader_begin(nx_n0, nx_co0);
+      if constexpr (WIN) issue_window(blk & 1);
+      issue_a(g & 1);
+      if constexpr (!WIN) issue_b_gather(g & 1);
+    }
+    char* scr_a = smem + ((g - 1) & 1) * A_STAGE;
+    char* patch;
+    float* eb;
+    if constexpr (WIN) {
+      char* scr_w = smem + W_BASE + ((blk - 1) & 1) * kWinBytes;
+      patch = wave < Cfg::NPW ? scr_w + wave * Cfg::PATCH : scr_a + (wave - Cfg::NPW) * Cfg::PATCH;
+      eb = reinterpret_cast<float*>(scr_a + (NW - Cfg::NPW) * Cfg::PATCH);
+    } else {
+      patch = scr_a + wave * Cfg::PATCH;
+      eb = reinterpret_cast<float*>(scr_a + NW * Cfg::PATCH);
+    }
+    epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
+    counted = true;
+    if (!more) break;
+    jt = jn;
+    cp_n0 = nx_n0;
+    cp_co0 = nx_co0;
+  }
+#endif
+}
+
 constexpr size_t dma_lds_bytes(int tc, int tr, bool win) {
   return win ? 2 * (size_t)tc * kRowBytes + 2 * (size_t)win_bytes(tr) : 2 * (size_t)(tr + tc) * kRowBytes;
 }
@@ -843,7 +1356,7 @@ inline size_t gn_lds_bytes(int tc, int cpg, int L) {
 
 template <typename T, int TC, int TR, bool WIN, bool GN>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
-  const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + a.tile_rows - 1) / a.tile_rows;
+  const int nco = (a.cout + TC - 1) / TC, nrow = a.row_tiles;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
   size_t lds = dma_lds_bytes(TC, TR, WIN);
   static bool attr_done = false;
@@ -867,6 +1380,32 @@ int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, bo
   if (tr == 128) return win ? launch_dma<T, 128, 128, true, false>(a, st) : launch_dma<T, 128, 128, false, false>(a, st);
   if (win) return tc == 256 ? launch_dma<T, 256, 256, true, false>(a, st) : launch_dma<T, 128, 256, true, false>(a, st);
   return tc == 256 ? launch_dma<T, 256, 256, false, false>(a, st) : launch_dma<T, 128, 256, false, false>(a, st);
+}
+
+template <typename T, int TC, int TR, bool WIN>
+int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
+  const int nco = (a.cout + TC - 1) / TC;
+  const int jt_end = nco * ((a.row_tiles + 7) / 8);
+  const int per_xcd = (cus / 8) * (TR == 128 ? 2 : 1);  // resident workgroups per XCD
+  const int nslot = jt_end < per_xcd ? jt_end : per_xcd;
+  size_t lds = dma_lds_bytes(TC, TR, WIN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      TDX_FAIL(TDX_ERR_HIP, "conv_gemm_stream: cannot reserve %zu bytes of LDS", lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
+  TDX_CHECK_LAUNCH("conv_gemm_stream_kernel");
+  return TDX_OK;
+}
+
+template <typename T>
+int dispatch_stream(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, int cus) {
+  if (tr == 128) return win ? launch_stream<T, 128, 128, true>(a, st, cus) : launch_stream<T, 128, 128, false>(a, st, cus);
+  if (win) return tc == 256 ? launch_stream<T, 256, 256, true>(a, st, cus) : launch_stream<T, 128, 256, true>(a, st, cus);
+  return tc == 256 ? launch_stream<T, 256, 256, false>(a, st, cus) : launch_stream<T, 128, 256, false>(a, st, cus);
 }
 
 }  // namespace
@@ -943,6 +1482,7 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   }
   dma_ok = dma_ok && (int64_t)kDmaRows * k * es < (1ll << 31);
   dma_ok = dma_ok && d->cout % vec == 0 && (!d->out || (d->out_off % vec == 0 && d->out_ld % vec == 0)) && (!d->res || d->res_ld % vec == 0);
+  dma_ok = dma_ok && (int64_t)(kDmaRows + 16) * d->out_ld * es < (1ll << 31);  // 32-bit in-tile store offsets
   const int tc = (d->cout % 256 == 0) ? 256 : 128;  // (128-wide tiles for Cout = 256 measured 17 % slower)
   const int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
   // narrow outputs: 128-row tiles, two workgroups per CU (epilogue of one under the K loop of the other)
@@ -971,7 +1511,60 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
     ch = Choice{win_ok ? 2 : 1, tc, tr, false};
     a.tile_rows = tr;
   }
+  a.n_begin = 0;
+  a.row_tiles = (a.N + a.tile_rows - 1) / a.tile_rows;
+  int c = 0;
+  while ((1ll << c) < d->lout) ++c;
+  a.div_k = 32 + c;
+  a.div_m = (uint64_t)((1ull << a.div_k) / (uint64_t)d->lout) + 1;
   return TDX_OK;
+}
+
+// Workgroup slots of 256-row tiles (one 8-wave workgroup per CU).
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <typename T>
+static int run_dma(ConvArgs& a, const Choice& ch, hipStream_t st) {
+  const bool win = ch.kind == 2;
+  // Persistent kernel: 128-channel tiles only by default.  With 256-channel tiles (128 accumulator registers per lane)
+  // hipcc spills loader state inside the K loop, and a spill reload is a vector-memory operation whose wait also waits
+  // for every DMA in flight; force bit 64 selects it anyway (tests, experiments).  The GroupNorm epilogue exists in
+  // the one-tile form only.
+  const bool stream = !ch.gn && !(g_force & 32);
+  auto go = [&](const ConvArgs& x, int tc, int tr) {
+    return stream && (tc == 128 || (g_force & 64)) ? dispatch_stream<T>(x, st, tc, tr, win, cu_count())
+                                                   : dispatch_dma<T>(x, st, tc, tr, win, ch.gn);
+  };
+  // Tail split.  256-row tiles run one per CU in rounds of cu_count() tiles of equal duration, so a last round that is
+  // only partly filled costs a whole round (e.g. 832 tiles = 3.25 rounds run as 4).  When the remainder is at most
+  // half a round, its rows are given to a second launch of 128 x 128 tiles instead (4x as many, <= two per CU,
+  // each about a fifth of a big tile's time).  Same K order per output element: results are bit-identical.
+  if (ch.tr == 256 && !ch.gn && !(g_force & 16)) {
+    const int cus = cu_count();
+    const int nco = (a.cout + ch.tc - 1) / ch.tc;
+    const int64_t tiles = (int64_t)a.row_tiles * nco;
+    const int64_t full = tiles / cus * cus, rem = tiles - full;
+    if (full > 0 && rem > 0 && rem <= g_tail_max && full % nco == 0) {
+      ConvArgs m = a;
+      m.row_tiles = (int32_t)(full / nco);
+      int rc = go(m, ch.tc, 256);
+      if (rc != TDX_OK) return rc;
+      ConvArgs t = a;
+      t.n_begin = m.row_tiles * kDmaRows;
+      t.tile_rows = 128;
+      t.row_tiles = (a.N - t.n_begin + 127) / 128;
+      return go(t, 128, 128);
+    }
+  }
+  return go(a, ch.tc, ch.tr);
 }
 
 extern "C" int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* d) {
@@ -986,19 +1579,19 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   const int rc = plan_conv(d, a, ch);
   if (rc != TDX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (ch.kind != 0) {
-    if (d->dtype == TDX_F32) return dispatch_dma<float>(a, st, ch.tc, ch.tr, ch.kind == 2, ch.gn);
-    return dispatch_dma<__bf16>(a, st, ch.tc, ch.tr, ch.kind == 2, ch.gn);
-  }
+  if (ch.kind != 0) return d->dtype == TDX_F32 ? run_dma<float>(a, ch, st) : run_dma<__bf16>(a, ch, st);
   if (d->dtype == TDX_F32) return launch<float, 128, 128>(a, st);
   return launch<__bf16, 128, 128>(a, st);
 }
 
 // Test hooks (not part of the reference-facing surface).
 // force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable,
-//             8 = never use the 128-row (two workgroups per CU) tiles.
+//             8 = never use the 128-row (two workgroups per CU) tiles, 16 = no tail split, 32 = one tile per workgroup
+//             (no persistent kernel), 64 = persistent kernel for 256-channel tiles too;
+//             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation).
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
-  g_force = bits;
+  g_force = bits & 0xff;
+  g_tail_max = (bits >> 8) & 0xff ? ((bits >> 8) & 0xff) * 2 : 128;
   return TDX_OK;
 }
 extern "C" int tdx_conv_gemm_debug(int32_t bits) {

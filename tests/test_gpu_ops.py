@@ -297,7 +297,7 @@ def test_groupnorm_act(dt, B, L, C, act):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,L,C", [(3, 13, 1024), (2, 16, 256), (1, 64, 128), (2, 1, 128)])
+@pytest.mark.parametrize("B,L,C", [(3, 13, 1024), (2, 16, 256), (1, 64, 128), (2, 1, 128), (9, 13, 96), (5, 7, 1024), (2, 17, 64)])
 def test_attention(dt, B, L, C):
     engine, _lib = _eng()
     g = torch.Generator().manual_seed(L)

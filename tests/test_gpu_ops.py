@@ -176,8 +176,8 @@ def test_conv_large_tiles_dma_kernel(dt, case):
         kw.update(tbias=torch.randn(Co + 8, generator=g))
     got = run_conv(dt, x, w, b, **kw)
     # 1: register-staged 128x128 kernel; 2: LDS-DMA without the shared tap window; 8: no 128-row tiles; 16: no tail launch;
-    # 32: one tile per workgroup instead of the persistent kernel
-    for bits in (1, 2, 8, 16, 32, 48, 34, 64, 80):
+    # 32: one tile per workgroup instead of the persistent kernel; 128: 128-channel tiles for every Cout
+    for bits in (1, 2, 8, 16, 32, 48, 34, 128):
         _lib.lib().tdx_conv_gemm_force_small(bits)
         try:
             other = run_conv(dt, x, w, b, **kw)

@@ -858,6 +858,12 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_dma_kernel(const ConvArgs p)
 // global stores are issued from asm and never waited for: the first K-step of the next tile waits with a
 // counted vmcnt that covers the DMAs (older) but not the stores (younger).  So the tile prologue (DMA latency),
 // the store drain and the workgroup launch all disappear under MFMA work instead of recurring per tile.
+// Explicit LDS accesses by 32-bit LDS address (a generic pointer that the compiler cannot trace back to the LDS array becomes
+// a flat access, and every flat access waits for vmcnt(0)).
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
+__device__ __forceinline__ f32x4 lds_ld16(uint32_t a) { return *reinterpret_cast<lds_f32x4_t*>(a); }
+__device__ __forceinline__ void lds_st16(uint32_t a, const f32x4& v) { *reinterpret_cast<lds_f32x4_t*>(a) = v; }
+
 __device__ __forceinline__ int fdiv(int n, uint64_t m, int k) { return (int)(((uint64_t)(uint32_t)n * m) >> k); }
 
 // 16-byte store through a buffer descriptor; lanes with an out-of-range offset are dropped by the hardware, so the
@@ -879,14 +885,14 @@ struct StreamCfg {
 };
 
 // Epilogue of the stream kernel, in two parts.
-//   epi_prefetch: every global READ of the epilogue (bias, per-step embed row, the tile's per-trajectory embed rows and,
-//     for 128-channel tiles, the residual vectors) is issued at the top of the tile's LAST K-step, into registers, and
-//     epi_pin makes the compiler wait for them right after that step's MFMAs, i.e. BEFORE the next tile's DMAs are
-//     issued.  vmcnt counts in issue order, so a read issued after those DMAs would wait for them too.
+//   prefetch: for 128-channel tiles every global READ of the epilogue (bias, per-step embed row, the tile's per-trajectory
+//     embed rows, the residual vectors) is issued with the tile's FIRST K-step, into registers, and pin() makes the
+//     compiler wait for them right after the last step's MFMAs, i.e. BEFORE the next tile's DMAs are issued (vmcnt
+//     counts in issue order, so a read issued after those DMAs would wait for them too).
 //   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
 //     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
 //     residual of 256-channel tiles (no registers to hold it during the K loop).
-template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES>
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES, bool RES>
 struct Epi {
   static constexpr bool PRE = PRE_RES;  // 256-channel tiles: no register room in the K loop, everything is read in finish()
   static constexpr int ES = (int)sizeof(T);
@@ -899,7 +905,7 @@ struct Epi {
   static constexpr int NST = NI * NH * NP;      // store instructions per wave per tile
   float bs[NH][VEC];
   f32x4 ebv[EBR];
-  u32x4 resv[NI][NH][NP];
+  u32x4 resv[RES ? NI : 1][NH][NP];
   int b_first, ntraj, n_end;
   bool eb_staged;
 
@@ -931,18 +937,18 @@ struct Epi {
     const int lane = opaque(lane_);
     const int c = lane % CPR;
     n_end = n0 + p.tile_rows < p.N ? n0 + p.tile_rows : p.N;
+    // (absent operands read a zero row instead of branching, so that all loads of the prefetch are issued back to back)
+    const float* zeros = reinterpret_cast<const float*>(g_zero_row);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int co = co0 + wc * WCO + h * PC + c * VEC;
+      const float* b1 = (p.bias && co < p.cout) ? p.bias + co : zeros;
+      const float* b2 = (p.tbias && co < p.cout) ? p.tbias + p.ebias_off + co : zeros;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) bs[h][j] = 0.f;
-      if (co < p.cout) {
-        if (p.bias)
+      for (int q = 0; q < VEC / 4; ++q) {
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(b1 + q * 4), t2 = *reinterpret_cast<const f32x4*>(b2 + q * 4);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) bs[h][j] += p.bias[co + j];
-        if (p.tbias)
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) bs[h][j] += p.tbias[p.ebias_off + co + j];
+        for (int j = 0; j < 4; ++j) bs[h][q * 4 + j] = (0.f + t1[j]) + t2[j];
       }
     }
     b_first = fdiv(n0, p.div_m, p.div_k);
@@ -959,7 +965,7 @@ struct Epi {
                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (PRE_RES && p.res) load_res(p, wr, wc, lane, n0, co0);
+    if constexpr (PRE_RES && RES) load_res(p, wr, wc, lane, n0, co0);
   }
 
   // Consume every prefetched register in an (empty) asm statement: the compiler's wait for the loads lands here.
@@ -971,7 +977,7 @@ struct Epi {
     if (eb_staged)
 #pragma unroll
       for (int k = 0; k < EBR; ++k) asm volatile("" : "+v"(ebv[k]));
-    if (PRE_RES && p.res)
+    if constexpr (PRE_RES && RES)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -981,14 +987,14 @@ struct Epi {
   }
 
   template <int MI>
-  __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], char* patch, float* eb_lds, int wave, int wr, int wc,
+  __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t patch, uint32_t eb_lds, int wave, int wr, int wc,
                                          int lane_, int n0, int co0) {
     const int lane = opaque(lane_);
     const int fr = lane & 15, fq = lane >> 4;
     const int c = lane % CPR, r0 = lane / CPR;
     const int cw = co0 + wc * WCO;  // first channel of this wave's tile
     if constexpr (!PRE) prefetch(p, wave, wr, wc, lane, n0, co0);
-    if (!PRE_RES && p.res) load_res(p, wr, wc, lane, n0, co0);
+    if constexpr (!PRE_RES && RES) load_res(p, wr, wc, lane, n0, co0);
     // output descriptor: base = first element of this wave's tile, range = rest of the output matrix
     const size_t obase = ((size_t)n0 * p.out_ld + p.out_off + cw) * ES;
     const size_t oleft = (size_t)p.N * p.out_ld * ES - obase;
@@ -999,7 +1005,7 @@ struct Epi {
 #pragma unroll
       for (int k = 0; k < EBR; ++k) {
         const int idx = tid_e + k * NT;
-        if (idx < ntraj * (TCH / 4)) *reinterpret_cast<f32x4*>(eb_lds + idx * 4) = ebv[k];
+        if (idx < ntraj * (TCH / 4)) lds_st16(eb_lds + idx * 16, ebv[k]);
       }
       __syncthreads();
     }
@@ -1008,8 +1014,7 @@ struct Epi {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
 #pragma unroll
-        for (int m = 0; m < PC / 16; ++m)
-          *reinterpret_cast<f32x4*>(patch + fr * STRIDE + (m * 16 + fq * 4) * 4) = acc[h * (PC / 16) + m][ni];
+        for (int m = 0; m < PC / 16; ++m) lds_st16(patch + fr * STRIDE + (m * 16 + fq * 4) * 4, acc[h * (PC / 16) + m][ni]);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
           const int row = r0 + RPP * i;
@@ -1018,7 +1023,7 @@ struct Epi {
           float v[VEC];
 #pragma unroll
           for (int q = 0; q < VEC / 4; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * STRIDE + (c * VEC + q * 4) * 4);
+            const f32x4 t = lds_ld16(patch + row * STRIDE + (c * VEC + q * 4) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[q * 4 + j] = t[j];
           }
@@ -1028,10 +1033,10 @@ struct Epi {
           if (p.ebias && live) {
             const int bb = fdiv(n, p.div_m, p.div_k);
             if (eb_staged) {  // (two separate branches: a pointer select would become flat loads, which wait for vmcnt(0))
-              const float* e = eb_lds + (bb - b_first) * TCH + wc * WCO + h * PC + c * VEC;
+              const uint32_t e = eb_lds + ((bb - b_first) * TCH + wc * WCO + h * PC + c * VEC) * 4;
 #pragma unroll
               for (int q = 0; q < VEC / 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(e + q * 4);
+                const f32x4 t = lds_ld16(e + q * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[q * 4 + j] += t[j];
               }
@@ -1047,7 +1052,7 @@ struct Epi {
           }
 #pragma unroll
           for (int j = 0; j < VEC; ++j) v[j] = tdx_act(v[j], p.act);
-          if (p.res) {
+          if constexpr (RES) {
             float rv[VEC];
             Elem<T>::unpack(resv[ni][h][i], rv);
 #pragma unroll
@@ -1061,7 +1066,7 @@ struct Epi {
   }
 };
 
-template <typename T, int TC, int TR, bool WIN>
+template <typename T, int TC, int TR, bool WIN, bool RES>
 __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using Cfg = StreamCfg<T, TC, TR>;
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   int jt = blockIdx.x >> 3, cp_n0, cp_co0;
   if (!tile_of(jt, cp_n0, cp_co0)) return;
 
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128>;
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128, RES>;
   // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
   int ld_n0 = 0;
   u32x4 rsrc_a, rsrc_b;
@@ -1209,21 +1214,12 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   const int sw = fr & 7;
   f32x4 acc[MI][NI];
   int cp_seg = 0, cp_ci = 0, cp_tap = 0, cp_taps = 1, cp_cin = 0;
-  uint32_t wmask = 0;
-  int wl[WIN ? NI : 1];
+  uint32_t wmask = 0, wm3 = 0, wm1 = 0;  // validity bits per (sub-tile, tap) of the current segment / of 3-tap and 1-tap segments
   auto cp_setup = [&]() {
     const SegDev& s = p.seg[cp_seg];
     cp_taps = s.taps;
     cp_cin = s.cin;
-    wmask = 0;
-#pragma unroll
-    for (int ni = 0; ni < (WIN ? NI : 0); ++ni)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int u = s.taps == 3 ? wl[ni] + t - 1 : wl[ni];
-        const bool ok = t < s.taps && wl[ni] >= 0 && u >= 0 && u < p.lout;
-        wmask |= (ok ? 1u : 0u) << (ni * 3 + t);
-      }
+    wmask = s.taps == 3 ? wm3 : wm1;
   };
   auto compute_begin = [&](int n0) {  // per tile
 #pragma unroll
@@ -1233,11 +1229,15 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     cp_seg = cp_ci = cp_tap = 0;
     if constexpr (WIN) {
       const int fr_o = EpiT::opaque(fr);  // (keeps the per-tile index math out of the registers that live across the K loop)
+      wm3 = wm1 = 0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int i_loc = wr * 64 + ni * 16 + fr_o;
         const int n = n0 + i_loc;
-        wl[ni] = (n < p.N && i_loc < p.tile_rows) ? n - fdiv(n, p.div_m, p.div_k) * p.lout : -1;
+        const bool row_ok = n < p.N && i_loc < p.tile_rows;
+        const int l = n - fdiv(n, p.div_m, p.div_k) * p.lout;  // position inside the trajectory
+        wm1 |= (row_ok ? 1u : 0u) << (ni * 3);
+        wm3 |= ((row_ok && l > 0 ? 1u : 0u) | (row_ok ? 2u : 0u) | (row_ok && l + 1 < p.lout ? 4u : 0u)) << (ni * 3);
       }
     }
     cp_setup();
@@ -1282,8 +1282,8 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   if constexpr (WIN) issue_window(0);
   issue_a(0);
   if constexpr (!WIN) issue_b_gather(0);
-  auto step = [&](auto last_c) {
-    constexpr bool LAST = decltype(last_c)::value != 0;
+  auto step = [&](auto first_c, auto last_c) {
+    constexpr bool FIRST = decltype(first_c)::value != 0, LAST = decltype(last_c)::value != 0;
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     counted = false;
@@ -1295,7 +1295,8 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     if constexpr (WIN) {
       if (cp_tap == 0 && ld_seg < p.nseg) issue_window((blk + 1) & 1);
     }
-    if constexpr (LAST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
+    // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
+    if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
     compute(g & 1, blk & 1);
     ++g;
     if (++cp_tap >= cp_taps) {
@@ -1311,8 +1312,18 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   };
   for (;;) {
     compute_begin(cp_n0);
-    for (int s = 0; s + 1 < p.nsteps; ++s) step(TapC<0>{});
-    step(TapC<1>{});
+    if constexpr (EpiT::PRE) {
+      if (p.nsteps == 1) {
+        step(TapC<1>{}, TapC<1>{});
+      } else {
+        step(TapC<1>{}, TapC<0>{});
+        for (int s = 1; s + 1 < p.nsteps; ++s) step(TapC<0>{}, TapC<0>{});
+        step(TapC<0>{}, TapC<1>{});
+      }
+    } else {
+      for (int s = 0; s + 1 < p.nsteps; ++s) step(TapC<0>{}, TapC<0>{});
+      step(TapC<0>{}, TapC<1>{});
+    }
     if constexpr (EpiT::PRE) epi.pin(p);
     // tile boundary: the loader goes ahead, then the epilogue runs in the buffers the last K-step released
     int nx_n0, nx_co0;
@@ -1324,19 +1335,30 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       issue_a(g & 1);
       if constexpr (!WIN) issue_b_gather(g & 1);
     }
-    char* scr_a = smem + ((g - 1) & 1) * A_STAGE;
-    char* patch;
-    float* eb;
+    const uint32_t scr_a = lds_base + ((g - 1) & 1) * A_STAGE;
+    uint32_t patch, eb;
     if constexpr (WIN) {
-      char* scr_w = smem + W_BASE + ((blk - 1) & 1) * kWinBytes;
+      const uint32_t scr_w = lds_base + W_BASE + ((blk - 1) & 1) * kWinBytes;
       patch = wave < Cfg::NPW ? scr_w + wave * Cfg::PATCH : scr_a + (wave - Cfg::NPW) * Cfg::PATCH;
-      eb = reinterpret_cast<float*>(scr_a + (NW - Cfg::NPW) * Cfg::PATCH);
+      eb = scr_a + (NW - Cfg::NPW) * Cfg::PATCH;
     } else {
       patch = scr_a + wave * Cfg::PATCH;
-      eb = reinterpret_cast<float*>(scr_a + NW * Cfg::PATCH);
+      eb = scr_a + NW * Cfg::PATCH;
     }
+#ifdef TDX_EXP_NOEPI
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+      if (t == 123.456f) p.out[cp_n0] = 1;
+      (void)patch; (void)eb;
+    }
+#else
     epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
     counted = true;
+#endif
     if (!more) break;
     jt = jn;
     cp_n0 = nx_n0;
@@ -1382,8 +1404,8 @@ int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, bo
   return tc == 256 ? launch_dma<T, 256, 256, false, false>(a, st) : launch_dma<T, 128, 256, false, false>(a, st);
 }
 
-template <typename T, int TC, int TR, bool WIN>
-int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
+template <typename T, int TC, int TR, bool WIN, bool RES>
+int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   const int nco = (a.cout + TC - 1) / TC;
   const int jt_end = nco * ((a.row_tiles + 7) / 8);
   const int per_xcd = (cus / 8) * (TR == 128 ? 2 : 1);  // resident workgroups per XCD
@@ -1391,14 +1413,19 @@ int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
   size_t lds = dma_lds_bytes(TC, TR, WIN);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_stream: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN, RES>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_stream_kernel");
   return TDX_OK;
+}
+
+template <typename T, int TC, int TR, bool WIN>
+int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
+  return a.res ? launch_stream2<T, TC, TR, WIN, true>(a, st, cus) : launch_stream2<T, TC, TR, WIN, false>(a, st, cus);
 }
 
 template <typename T>
@@ -1534,14 +1561,10 @@ static int cu_count() {
 template <typename T>
 static int run_dma(ConvArgs& a, const Choice& ch, hipStream_t st) {
   const bool win = ch.kind == 2;
-  // Persistent kernel: 128-channel tiles only by default.  With 256-channel tiles (128 accumulator registers per lane)
-  // hipcc spills loader state inside the K loop, and a spill reload is a vector-memory operation whose wait also waits
-  // for every DMA in flight; force bit 64 selects it anyway (tests, experiments).  The GroupNorm epilogue exists in
-  // the one-tile form only.
+  // Persistent kernel for every tile shape; the GroupNorm epilogue exists in the one-tile-per-workgroup form only.
   const bool stream = !ch.gn && !(g_force & 32);
   auto go = [&](const ConvArgs& x, int tc, int tr) {
-    return stream && (tc == 128 || (g_force & 64)) ? dispatch_stream<T>(x, st, tc, tr, win, cu_count())
-                                                   : dispatch_dma<T>(x, st, tc, tr, win, ch.gn);
+    return stream ? dispatch_stream<T>(x, st, tc, tr, win, cu_count()) : dispatch_dma<T>(x, st, tc, tr, win, ch.gn);
   };
   // Tail split.  256-row tiles run one per CU in rounds of cu_count() tiles of equal duration, so a last round that is
   // only partly filled costs a whole round (e.g. 832 tiles = 3.25 rounds run as 4).  When the remainder is at most
@@ -1587,7 +1610,7 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
 // Test hooks (not part of the reference-facing surface).
 // force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable,
 //             8 = never use the 128-row (two workgroups per CU) tiles, 16 = no tail split, 32 = one tile per workgroup
-//             (no persistent kernel), 64 = persistent kernel for 256-channel tiles too;
+//             (no persistent kernel), 128 = 128-channel tiles for every Cout;
 //             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation).
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   g_force = bits & 0xff;

@@ -47,21 +47,23 @@ for name, L, ci, co, k in SHAPES:
     if len(pg.ops) != 1:
         continue
     fl = 2.0 * B * L * co * k * ci
-    cells = []
-    for f, d in [(f, d) for f in forces for d in a.debug]:
-        lib.tdx_conv_gemm_force_small(f)
-        lib.tdx_conv_gemm_debug(d)
-        for _ in range(3):
-            pg.run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            pg.run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        cells.append(f"{ms:7.3f} / {fl / ms / 1e9:6.0f}")
+    combos = [(f, d) for f in forces for d in a.debug]
+    best = [1e9] * len(combos)
+    for rnd in range(4):  # interleaved rounds, best of 4: clocks drift by a few % within a process
+        for ci, (f, d) in enumerate(combos):
+            lib.tdx_conv_gemm_force_small(f)
+            lib.tdx_conv_gemm_debug(d)
+            for _ in range(2):
+                pg.run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                pg.run()
+            e1.record()
+            torch.cuda.synchronize()
+            best[ci] = min(best[ci], e0.elapsed_time(e1) / 10)
+    cells = [f"{ms:7.3f} / {fl / ms / 1e9:6.0f}" for ms in best]
     lib.tdx_conv_gemm_debug(0)
     lib.tdx_conv_gemm_force_small(0)
     print(f"{name:22s} " + "   ".join(cells))

@@ -1253,18 +1253,24 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       boff[ni] = wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4);
       if constexpr (WIN) boff[ni] = ((wmask >> (ni * 3 + cp_tap)) & 1u) ? boff[ni] : kWinGroups * 8 * kRowBytes;
     }
+    // Fragment reads are software-pipelined by hand: the weight fragment of sub-tile row t + 2 and the activation
+    // fragments of the second K half are requested while the MFMAs of row t run (left to itself hipcc reads one
+    // weight fragment, waits for it, issues its four MFMAs, and so exposes an LDS round trip per four MFMAs).
+    constexpr int NT2 = 2 * MI;  // (kk, mi) pairs
+    auto a_addr = [&](int t) { return a + a_frag + (t % MI) * 16 * kRowBytes + (((((t / MI) << 2) + fq) ^ sw) << 4); };
+    u32x4 bf[2][NI], af[3];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = (((kk << 2) + fq) ^ sw) << 4;
-      u32x4 af[MI], bf[NI];
+    for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const u32x4*>(b + boff[ni]);
+    af[0] = *reinterpret_cast<const u32x4*>(a_addr(0));
+    af[1] = *reinterpret_cast<const u32x4*>(a_addr(1));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(b + (boff[ni] ^ (kk << 6)));
+    for (int t = 0; t < NT2; ++t) {
+      if (t + 2 < NT2) af[(t + 2) % 3] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
+      if (t < NI) bf[1][t] = *reinterpret_cast<const u32x4*>(b + (boff[t] ^ 64));  // second K half, one fragment per row of the first
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs of this row (the scheduler would sink them to their uses)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(a + a_frag + mi * 16 * kRowBytes + ch);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[mi], bf[ni], acc[mi][ni]);
+      for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[t % 3], bf[t / MI][ni], acc[t % MI][ni]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -1282,18 +1288,35 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   if constexpr (WIN) issue_window(0);
   issue_a(0);
   if constexpr (!WIN) issue_b_gather(0);
+  // vmcnt counts in issue order.  A window is issued AFTER the weight stage of its step, so that the next step can wait
+  // for that stage alone (vmcnt = number of window DMAs) and the window gets two K-steps to arrive instead of one.
+  const int win_dmas = GW - ((wave + NW * (GW - 1) < kWinGroups) ? 0 : 1);  // window DMAs this wave issues per window
+  int pend_w = 0;                                                            // ... of them issued in the previous K-step
+  auto wait_vm = [&](int n) {
+    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == GW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW - 1) : "memory");
+  };
   auto step = [&](auto first_c, auto last_c) {
     constexpr bool FIRST = decltype(first_c)::value != 0, LAST = decltype(last_c)::value != 0;
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_vm(cp_tap == 0 ? 0 : pend_w);  // (a block's first step needs its window)
     counted = false;
     __syncthreads();
     if constexpr (!LAST) {
+#ifndef TDX_EXP_NOA
       issue_a((g + 1) & 1);
+#endif
       if constexpr (!WIN) issue_b_gather((g + 1) & 1);
     }
+    pend_w = 0;
     if constexpr (WIN) {
-      if (cp_tap == 0 && ld_seg < p.nseg) issue_window((blk + 1) & 1);
+#ifndef TDX_EXP_NOW
+      if (cp_tap == 0 && ld_seg < p.nseg) {
+        issue_window((blk + 1) & 1);
+        pend_w = win_dmas;
+      }
+#endif
     }
     // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
     if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);

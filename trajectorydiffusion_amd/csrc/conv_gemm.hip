@@ -875,13 +875,13 @@ __device__ __forceinline__ void buf_store16(const u32x4& v, uint32_t voff, const
 template <typename T, int TC, int TR>
 struct StreamCfg {
   static constexpr int NW = TR / 32;
-  static constexpr int PATCH = 16 * (64 * 4 + 16);             // one wave's transpose patch: 16 rows x 64 fp32 channels, padded
+  static constexpr int PATCH = 2 * 16 * (32 * 4 + 16);         // one wave's two transpose pieces (16 rows x 32 fp32 channels, padded)
   static constexpr int WU = win_groups(TR) * 8 * kRowBytes;    // window bytes below its zero row
-  static constexpr int NPW = WU / PATCH < NW ? WU / PATCH : NW;  // window mode: patches that fit the released window
+  static constexpr int NPW = WU / PATCH < NW ? WU / PATCH : NW;  // window mode: waves whose pieces fit the released window
   static constexpr int EBT = TR == 256 ? 22 : 12;              // embed-bias rows staged per tile (trajectories touched)
-  static constexpr int NST = 4 * (TC / 2 / 64) * (16 / (64 / (64 / (16 / (int)sizeof(T)))));  // stores per wave per tile
-  static_assert((NW - NPW) * PATCH + EBT * TC * 4 <= TC * kRowBytes, "window-mode epilogue scratch does not fit the released weight stage");
-  static_assert(NW * PATCH + EBT * TC * 4 <= (TC + TR) * kRowBytes, "gather-mode epilogue scratch does not fit the released stage");
+  static constexpr int NST = 4 * (TC / 2 / 32) * (16 / (64 / (32 / (16 / (int)sizeof(T)))));  // stores per wave per tile
+  static_assert((NW - NPW) * PATCH + (EBT + 1) * TC * 4 <= TC * kRowBytes, "window-mode epilogue scratch does not fit the released weight stage");
+  static_assert(NW * PATCH + (EBT + 1) * TC * 4 <= (TC + TR) * kRowBytes, "gather-mode epilogue scratch does not fit the released stage");
 };
 
 // Epilogue of the stream kernel, in two parts.
@@ -892,20 +892,20 @@ struct StreamCfg {
 //   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
 //     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
 //     residual of 256-channel tiles (no registers to hold it during the K loop).
-template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES, bool RES>
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES, bool RES, bool EB>
 struct Epi {
   static constexpr bool PRE = PRE_RES;  // 256-channel tiles: no register room in the K loop, everything is read in finish()
   static constexpr int ES = (int)sizeof(T);
   static constexpr int VEC = 16 / ES;
-  static constexpr int PC = 64, NH = WCO / PC;  // channels per transpose pass, passes per sub-tile row
-  static constexpr int STRIDE = PC * 4 + 16;
+  static constexpr int PC = 32, NQ = WCO / PC;  // channels per transposed piece, pieces per sub-tile row
+  static constexpr int STRIDE = PC * 4 + 16;    // fp32 piece row, padded: conflict-free ds_write_b128
+  static constexpr int PIECE = 16 * STRIDE;     // a wave owns two of them (double buffer)
   static constexpr int CPR = PC / VEC, RPP = 64 / CPR, NP = 16 / RPP;
   static constexpr int NT = NWV * 64;
-  static constexpr int EBR = (EBT * (TCH / 4) + NT - 1) / NT;
-  static constexpr int NST = NI * NH * NP;      // store instructions per wave per tile
-  float bs[NH][VEC];
+  static constexpr int EBR = ((EBT + 1) * (TCH / 4) + NT - 1) / NT;  // staged rows: [0] = bias + time-step row, [1 + t] = trajectory t
+  static constexpr int NST = NI * NQ * NP;      // store instructions per wave per tile
   f32x4 ebv[EBR];
-  u32x4 resv[RES ? NI : 1][NH][NP];
+  u32x4 resv[RES ? NI : 1][NQ][NP];
   int b_first, ntraj, n_end;
   bool eb_staged;
 
@@ -923,46 +923,43 @@ struct Epi {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int h = 0; h < NH; ++h)
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
           const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
-          const int co = co0 + wc * WCO + h * PC + c * VEC;
-          resv[ni][h][i] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES)
+          const int co = co0 + wc * WCO + q * PC + c * VEC;
+          resv[ni][q][i] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES)
                                                       : (u32x4){0u, 0u, 0u, 0u};
         }
   }
 
+  // Global reads of the epilogue into registers: the rows that go to LDS (bias + time-step row, the tile's per-trajectory
+  // embed rows; absent operands read a zero row instead of branching, so all loads are issued back to back) and, when
+  // PRE_RES, the residual vectors.
   __device__ __forceinline__ void prefetch(const ConvArgs& p, int wave, int wr, int wc, int lane_, int n0, int co0) {
     const int lane = opaque(lane_);
-    const int c = lane % CPR;
     n_end = n0 + p.tile_rows < p.N ? n0 + p.tile_rows : p.N;
-    // (absent operands read a zero row instead of branching, so that all loads of the prefetch are issued back to back)
-    const float* zeros = reinterpret_cast<const float*>(g_zero_row);
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const int co = co0 + wc * WCO + h * PC + c * VEC;
-      const float* b1 = (p.bias && co < p.cout) ? p.bias + co : zeros;
-      const float* b2 = (p.tbias && co < p.cout) ? p.tbias + p.ebias_off + co : zeros;
-#pragma unroll
-      for (int q = 0; q < VEC / 4; ++q) {
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(b1 + q * 4), t2 = *reinterpret_cast<const f32x4*>(b2 + q * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[h][q * 4 + j] = (0.f + t1[j]) + t2[j];
-      }
-    }
     b_first = fdiv(n0, p.div_m, p.div_k);
     ntraj = fdiv(n_end - 1, p.div_m, p.div_k) - b_first + 1;
-    eb_staged = p.ebias && ntraj <= EBT;
-    if (eb_staged) {
-      const int tid_e = wave * 64 + lane;
+    eb_staged = EB && p.ebias && ntraj <= EBT;
+    const float* zeros = reinterpret_cast<const float*>(g_zero_row);
+    const int tid_e = wave * 64 + lane;
 #pragma unroll
-      for (int k = 0; k < EBR; ++k) {
-        const int idx = tid_e + k * NT;
-        const int t = idx / (TCH / 4), q4 = idx - t * (TCH / 4);
-        const int cc = co0 + q4 * 4;
-        ebv[k] = (t < ntraj && cc < p.cout) ? *reinterpret_cast<const f32x4*>(p.ebias + (size_t)(b_first + t) * p.ebias_ld + p.ebias_off + cc)
-                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < EBR; ++k) {
+      const int idx = tid_e + k * NT;
+      const int t = idx / (TCH / 4), q4 = idx - t * (TCH / 4);
+      const int cc = co0 + q4 * 4;
+      const bool col = cc < p.cout;
+      if (k == 0 && (TCH / 4) <= NT) {  // slot 0 holds row 0 (and the first trajectory rows)
+        const float* b1 = (t == 0 && p.bias && col) ? p.bias + cc : zeros;
+        const float* b2 = (t == 0 && p.tbias && col) ? p.tbias + p.ebias_off + cc : zeros;
+        const float* e = (t >= 1 && eb_staged && t - 1 < ntraj && col) ? p.ebias + (size_t)(b_first + t - 1) * p.ebias_ld + p.ebias_off + cc : zeros;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(b1), v2 = *reinterpret_cast<const f32x4*>(b2), v3 = *reinterpret_cast<const f32x4*>(e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ebv[k][j] = ((0.f + v1[j]) + v2[j]) + v3[j];  // row 0: bias + tbias (v3 = 0); rows >= 1: 0 + 0 + e
+      } else {
+        const float* e = (eb_staged && t >= 1 && t - 1 < ntraj && col) ? p.ebias + (size_t)(b_first + t - 1) * p.ebias_ld + p.ebias_off + cc : zeros;
+        ebv[k] = *reinterpret_cast<const f32x4*>(e);
       }
     }
     if constexpr (PRE_RES && RES) load_res(p, wr, wc, lane, n0, co0);
@@ -971,24 +968,21 @@ struct Epi {
   // Consume every prefetched register in an (empty) asm statement: the compiler's wait for the loads lands here.
   __device__ __forceinline__ void pin(const ConvArgs& p) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) asm volatile("" : "+v"(bs[h][j]));
-    if (eb_staged)
-#pragma unroll
-      for (int k = 0; k < EBR; ++k) asm volatile("" : "+v"(ebv[k]));
+    for (int k = 0; k < EBR; ++k) asm volatile("" : "+v"(ebv[k]));
     if constexpr (PRE_RES && RES)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(resv[ni][h][i]));
+          for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(resv[ni][q][i]));
   }
 
+  // patch: LDS address of this wave's two pieces; eb_lds: LDS address of the staged rows.
   template <int MI>
   __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t patch, uint32_t eb_lds, int wave, int wr, int wc,
                                          int lane_, int n0, int co0) {
+    static_assert(TCH / 4 <= NT, "one staging slot must cover a whole row");
     const int lane = opaque(lane_);
     const int fr = lane & 15, fq = lane >> 4;
     const int c = lane % CPR, r0 = lane / CPR;
@@ -1000,74 +994,114 @@ struct Epi {
     const size_t oleft = (size_t)p.N * p.out_ld * ES - obase;
     const u32x4 rsrc_o = make_srd(p.out + obase, oleft > 0x7fffffffull ? 0x7fffffffu : (uint32_t)oleft);
     __syncthreads();  // every wave is done with the K loop's last buffers: they are epilogue scratch now
-    if (eb_staged) {
+    {
       const int tid_e = wave * 64 + lane;
 #pragma unroll
       for (int k = 0; k < EBR; ++k) {
         const int idx = tid_e + k * NT;
-        if (idx < ntraj * (TCH / 4)) lds_st16(eb_lds + idx * 16, ebv[k]);
+        if (idx < (1 + (eb_staged ? ntraj : 0)) * (TCH / 4)) lds_st16(eb_lds + idx * 16, ebv[k]);
       }
-      __syncthreads();
     }
+    __syncthreads();
+    // Pieces of 16 rows x 32 channels, two LDS buffers per wave, software-pipelined: piece k + 1 is written and piece k is
+    // read back (transposed: a lane gets 16 bytes of output of one row) before the arithmetic of piece k starts, so no
+    // LDS round trip is waited for with nothing else to do.  (LDS operations of a wave execute in order: the write of
+    // piece k + 2 into the buffer of piece k cannot overtake the read of piece k.)
+    constexpr int NPC = NI * NQ;
+    auto put = [&](int k) {  // k = ni * NQ + q
+      const int ni = k / NQ, q = k % NQ;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+      for (int m = 0; m < PC / 16; ++m)
+        lds_st16(patch + (k & 1) * PIECE + fr * STRIDE + (m * 16 + fq * 4) * 4, acc[q * (PC / 16) + m][ni]);
+    };
+    // what the arithmetic of one piece reads from LDS: its transposed values, the bias row and (staged) embed rows
+    struct Piece {
+      f32x4 d[NP][VEC / 4], bs[VEC / 4], eb[EB ? NP : 1][VEC / 4];
+    };
+    const bool eb_lds_on = EB && p.ebias && eb_staged;
+    auto get = [&](int k, Piece& x) {
+      const int ni = k / NQ, q = k % NQ;
+      const int chl = wc * WCO + q * PC + c * VEC;
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
+      for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int m = 0; m < PC / 16; ++m) lds_st16(patch + fr * STRIDE + (m * 16 + fq * 4) * 4, acc[h * (PC / 16) + m][ni]);
+        for (int h = 0; h < VEC / 4; ++h) x.d[i][h] = lds_ld16(patch + (k & 1) * PIECE + (r0 + RPP * i) * STRIDE + (c * VEC + h * 4) * 4);
+#pragma unroll
+      for (int h = 0; h < VEC / 4; ++h) x.bs[h] = lds_ld16(eb_lds + (chl + h * 4) * 4);
+      if constexpr (EB) if (eb_lds_on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          const int row = r0 + RPP * i;
-          const int row_local = wr * 64 + ni * 16 + row;
-          const int n = n0 + row_local;
-          float v[VEC];
+          const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
+          int t = fdiv(n < n_end ? n : n_end - 1, p.div_m, p.div_k) - b_first;  // (rows past the end are never stored)
 #pragma unroll
-          for (int q = 0; q < VEC / 4; ++q) {
-            const f32x4 t = lds_ld16(patch + row * STRIDE + (c * VEC + q * 4) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[q * 4 + j] = t[j];
-          }
-          const bool live = n < n_end && cw + h * PC + c * VEC < p.cout;
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) v[j] += bs[h][j];
-          if (p.ebias && live) {
-            const int bb = fdiv(n, p.div_m, p.div_k);
-            if (eb_staged) {  // (two separate branches: a pointer select would become flat loads, which wait for vmcnt(0))
-              const uint32_t e = eb_lds + ((bb - b_first) * TCH + wc * WCO + h * PC + c * VEC) * 4;
-#pragma unroll
-              for (int q = 0; q < VEC / 4; ++q) {
-                const f32x4 t = lds_ld16(e + q * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[q * 4 + j] += t[j];
-              }
-            } else {
-              const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + cw + h * PC + c * VEC;
-#pragma unroll
-              for (int q = 0; q < VEC / 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(e + q * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[q * 4 + j] += t[j];
-              }
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) v[j] = tdx_act(v[j], p.act);
-          if constexpr (RES) {
-            float rv[VEC];
-            Elem<T>::unpack(resv[ni][h][i], rv);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v[j] += rv[j];
-          }
-          const uint32_t voff = live ? (uint32_t)(row_local * p.out_ld + h * PC + c * VEC) * ES : kOob;
-          buf_store16(Elem<T>::pack(v), voff, rsrc_o);
+          for (int h = 0; h < VEC / 4; ++h) x.eb[i][h] = lds_ld16(eb_lds + ((1 + t) * TCH + chl + h * 4) * 4);
         }
       }
+    };
+    Piece cur, nxt;
+    put(0);
+    if (NPC > 1) put(1);
+    get(0, cur);
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int ni = k / NQ, q = k % NQ;
+      if (k + 1 < NPC) get(k + 1, nxt);
+      if (k + 2 < NPC) put(k + 2);
+      const int chl = wc * WCO + q * PC + c * VEC;  // channel inside the block tile
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int row_local = wr * 64 + ni * 16 + r0 + RPP * i;
+        const int n = n0 + row_local;
+        const bool live = n < n_end && co0 + chl < p.cout;
+        float v[VEC];
+#pragma unroll
+        for (int h = 0; h < VEC / 4; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[h * 4 + j] = cur.d[i][h][j] + cur.bs[h][j];
+        if constexpr (EB) if (eb_lds_on) {
+#pragma unroll
+          for (int h = 0; h < VEC / 4; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[h * 4 + j] += cur.eb[i][h][j];
+        } else if (p.ebias && live) {  // more trajectories in the tile than staged rows: read the rows from global memory
+          const int bb = fdiv(n, p.div_m, p.div_k);
+          const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co0 + chl;
+#pragma unroll
+          for (int h = 0; h < VEC / 4; ++h) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+          }
+        }
+        if (p.act == TDX_ACT_SWISH) {  // one wave-uniform branch per vector, not one per element
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = tdx_swish(v[j]);
+        } else if (p.act == TDX_ACT_LEAKY) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = tdx_leaky(v[j]);
+        }
+        if constexpr (RES) {
+          float rv[VEC];
+          Elem<T>::unpack(resv[ni][q][i], rv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += rv[j];
+        }
+        const uint32_t voff = live ? (uint32_t)(row_local * p.out_ld + q * PC + c * VEC) * ES : kOob;
+#ifdef TDX_EXP_NOSTORE
+        { u32x4 pk = Elem<T>::pack(v); asm volatile("" ::"v"(pk), "v"(voff)); }
+#else
+        buf_store16(Elem<T>::pack(v), voff, rsrc_o);
+#endif
+      }
+      cur = nxt;
     }
   }
 };
 
-template <typename T, int TC, int TR, bool WIN, bool RES>
+// MODE: 0 = no per-trajectory embed rows and no residual, 1 = embed rows, 2 = residual (both at once: one-tile kernel).
+template <typename T, int TC, int TR, bool WIN, int MODE>
 __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs p) {
+  constexpr bool RES = MODE == 2, EB = MODE == 1;
 #if defined(__HIP_DEVICE_COMPILE__)
   using Cfg = StreamCfg<T, TC, TR>;
   constexpr int ES = (int)sizeof(T);
@@ -1105,7 +1139,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   int jt = blockIdx.x >> 3, cp_n0, cp_co0;
   if (!tile_of(jt, cp_n0, cp_co0)) return;
 
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128, RES>;
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128, RES, EB>;
   // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
   int ld_n0 = 0;
   u32x4 rsrc_a, rsrc_b;
@@ -1242,7 +1276,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     }
     cp_setup();
   };
-  auto compute = [&](int abuf, int wbuf) {
+  auto compute = [&](int abuf, int wbuf, auto&& mid) {
     const char* a = smem + abuf * A_STAGE;
     const char* b = WIN ? smem + W_BASE + wbuf * kWinBytes : a + A_BYTES;
     int boff[NI];
@@ -1265,6 +1299,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     af[1] = *reinterpret_cast<const u32x4*>(a_addr(1));
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
+      // The step's DMA issue sits behind the first row of MFMAs: right after the barrier the MFMA pipe is empty, and
+      // the DMA instructions (m0 set-up, s_nop, issue) would keep it empty for their whole issue time.
+      if (t == 1) mid();
       if (t + 2 < NT2) af[(t + 2) % 3] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
       if (t < NI) bf[1][t] = *reinterpret_cast<const u32x4*>(b + (boff[t] ^ 64));  // second K half, one fragment per row of the first
       __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs of this row (the scheduler would sink them to their uses)
@@ -1302,25 +1339,29 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
     else wait_vm(cp_tap == 0 ? 0 : pend_w);  // (a block's first step needs its window)
     counted = false;
+#ifndef TDX_EXP_NOBAR
     __syncthreads();
-    if constexpr (!LAST) {
-#ifndef TDX_EXP_NOA
-      issue_a((g + 1) & 1);
 #endif
-      if constexpr (!WIN) issue_b_gather((g + 1) & 1);
-    }
+    const int g_now = g, blk_now = blk, tap_now = cp_tap;
     pend_w = 0;
-    if constexpr (WIN) {
-#ifndef TDX_EXP_NOW
-      if (cp_tap == 0 && ld_seg < p.nseg) {
-        issue_window((blk + 1) & 1);
-        pend_w = win_dmas;
-      }
+    compute(g & 1, blk & 1, [&]() {
+      if constexpr (!LAST) {
+#ifndef TDX_EXP_NOA
+        issue_a((g_now + 1) & 1);
 #endif
-    }
-    // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
-    if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
-    compute(g & 1, blk & 1);
+        if constexpr (!WIN) issue_b_gather((g_now + 1) & 1);
+      }
+      if constexpr (WIN) {
+#ifndef TDX_EXP_NOW
+        if (tap_now == 0 && ld_seg < p.nseg) {
+          issue_window((blk_now + 1) & 1);
+          pend_w = win_dmas;
+        }
+#endif
+      }
+      // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
+      if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
+    });
     ++g;
     if (++cp_tap >= cp_taps) {
       cp_tap = 0;
@@ -1380,7 +1421,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     }
 #else
     epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
+#ifndef TDX_EXP_NOSTORE
     counted = true;
+#endif
 #endif
     if (!more) break;
     jt = jn;
@@ -1427,7 +1470,7 @@ int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, bo
   return tc == 256 ? launch_dma<T, 256, 256, false, false>(a, st) : launch_dma<T, 128, 256, false, false>(a, st);
 }
 
-template <typename T, int TC, int TR, bool WIN, bool RES>
+template <typename T, int TC, int TR, bool WIN, int MODE>
 int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   const int nco = (a.cout + TC - 1) / TC;
   const int jt_end = nco * ((a.row_tiles + 7) / 8);
@@ -1436,19 +1479,36 @@ int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   size_t lds = dma_lds_bytes(TC, TR, WIN);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, RES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_stream: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN, RES>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN, MODE>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_stream_kernel");
   return TDX_OK;
 }
 
+// Shapes the persistent kernel is built for.  The rest (no register room: hipcc would spill inside the K loop, see
+// scripts/check_spills.py) run on the one-tile-per-workgroup kernel, with identical results:
+//   embed rows together with a residual; a residual on gathered 256-channel tiles; fp32 256-channel tiles with a residual,
+//   or gathered with embed rows.
+template <typename T>
+constexpr bool stream_ok(int tc, bool win, int mode) {
+  if (mode == 3) return false;
+  if (tc == 256 && mode == 2 && (!win || sizeof(T) == 4)) return false;
+  if (tc == 256 && mode == 1 && !win && sizeof(T) == 4) return false;
+  return true;
+}
+inline int conv_mode(const ConvArgs& a) { return (a.res ? 2 : 0) | (a.ebias ? 1 : 0); }
+
 template <typename T, int TC, int TR, bool WIN>
 int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
-  return a.res ? launch_stream2<T, TC, TR, WIN, true>(a, st, cus) : launch_stream2<T, TC, TR, WIN, false>(a, st, cus);
+  const int mode = conv_mode(a);
+  if constexpr (stream_ok<T>(TC, WIN, 2)) if (mode == 2) return launch_stream2<T, TC, TR, WIN, 2>(a, st, cus);
+  if constexpr (stream_ok<T>(TC, WIN, 1)) if (mode == 1) return launch_stream2<T, TC, TR, WIN, 1>(a, st, cus);
+  if (mode == 0) return launch_stream2<T, TC, TR, WIN, 0>(a, st, cus);
+  TDX_FAIL(TDX_ERR_UNSUPPORTED, "conv_gemm_stream: internal dispatch error (tc=%d win=%d mode=%d)", TC, (int)WIN, mode);
 }
 
 template <typename T>
@@ -1587,7 +1647,8 @@ static int run_dma(ConvArgs& a, const Choice& ch, hipStream_t st) {
   // Persistent kernel for every tile shape; the GroupNorm epilogue exists in the one-tile-per-workgroup form only.
   const bool stream = !ch.gn && !(g_force & 32);
   auto go = [&](const ConvArgs& x, int tc, int tr) {
-    return stream ? dispatch_stream<T>(x, st, tc, tr, win, cu_count()) : dispatch_dma<T>(x, st, tc, tr, win, ch.gn);
+    return stream && stream_ok<T>(tc, win, conv_mode(x)) ? dispatch_stream<T>(x, st, tc, tr, win, cu_count())
+                                                         : dispatch_dma<T>(x, st, tc, tr, win, ch.gn);
   };
   // Tail split.  256-row tiles run one per CU in rounds of cu_count() tiles of equal duration, so a last round that is
   // only partly filled costs a whole round (e.g. 832 tiles = 3.25 rounds run as 4).  When the remainder is at most

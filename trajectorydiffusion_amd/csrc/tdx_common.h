@@ -62,9 +62,11 @@ struct Elem<__bf16> {
   static __device__ __forceinline__ u32x4 pack(const float (&o)[8]) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __bf16 lo = (__bf16)o[2 * i], hi = (__bf16)o[2 * i + 1];  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
-      v[i] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+    for (int i = 0; i < 4; ++i) {  // RNE, NaN-preserving; a two-element vector conversion is ONE v_cvt_pk_bf16_f32
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t f = {o[2 * i], o[2 * i + 1]};
+      v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
     }
     return v;
   }

@@ -144,7 +144,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "diffusion_steps": a.T, "parallelism": f"batch-shard x{world}"},
             "ms_per_denoise_step": round(1e3 * elapsed / a.steps / n_denoise, 4),
             "model_tflops": round(value * n_denoise * FLOP_PER_TRAJ_STEP / 1e12 / world, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_dma_kernel, tdx_conv_gemm (all %d launches of one denoise step)" % len(gemm),
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call = main grid + optional small-tile tail grid; all %d calls of one denoise step)" % len(gemm),
                          "achieved": round(achieved, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.dtype], 4),
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, bytes per launch, avg of 38)",
                          "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * 2 * B / 38) if a.dtype == "bf16" else None, "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),

@@ -1,0 +1,13 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r1b; rm -rf $O; mkdir -p $O
+timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 100 python scripts/op_breakdown.py > $O/op_breakdown.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 1 --warmup 0 --T 50 --no-cpu-baseline --no-graph > $O/kt.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph > $O/fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph > $O/write.log 2>&1
+find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find $O/fetch -name "*counter_collection.csv" -exec cp {} $O/fetch.csv \;
+find $O/write -name "*counter_collection.csv" -exec cp {} $O/write.csv \;
+rm -rf $O/kt $O/fetch $O/write
+ls -la $O; head -c 600 $O/bench.json

@@ -2,6 +2,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r1b; rm -rf $O; mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 400 python bench.py --sampler ddim --batch 65536 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_ddim_B65536.json 2>> $O/bench.err
 timeout -k 10 100 python scripts/op_breakdown.py > $O/op_breakdown.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 1 --warmup 0 --T 50 --no-cpu-baseline --no-graph > $O/kt.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph > $O/fetch.log 2>&1

@@ -182,3 +182,62 @@ def test_generic_model_path_and_ddim(model, sd):
             e = trajunet_forward(sd, x, torch.full((B,), t), cat, num, FULL_SCHEDULE, T_MODEL)
             x = o.ddim_step(x, t, ts[i + 1] if i + 1 < len(ts) else -1, e)
     assert rel(got, x) < 5e-4
+
+
+def test_full_size_c2_properties(model, sd):
+    """BASELINE config C2 (B=4096, L=200): the oracle cannot run 4096 trajectories in seconds, so the full-size batch is
+    pinned by (a) the oracle on a sample of its trajectories (each trajectory is independent of the rest of the batch),
+    (b) batch-shard invariance, bit for bit, of one forward and of a Philox-driven sampling run (the multi-GPU
+    partition), in fp32 and bf16."""
+    from trajectorydiffusion_amd import DiffusionManager
+    B, L = 4096, 200
+    x, t, cat, num = synth_inputs(B, L, T_MODEL, seed=11)
+    xg, tg, cg, ng = x.cuda(), t.cuda(), cat.cuda(), num.cuda()
+    pick = torch.tensor([0, 1337, 2048, 4095])
+    with torch.no_grad():
+        ref = trajunet_forward(sd, x[pick], t[pick], cat[pick], num[pick], FULL_SCHEDULE, T_MODEL)
+    try:
+        for dt, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, 3 * BF16_TOL)):
+            model.set_compute_dtype(dt)
+            eps = model(xg, tg, cg, ng)
+            assert torch.isfinite(eps).all()
+            assert rel(eps[pick.cuda()].cpu(), ref) < tol, dt
+            part = model(xg[1024:2048], tg[1024:2048], cg[1024:2048], ng[1024:2048])   # another batch size, other tiles
+            assert torch.equal(part, eps[1024:2048]), dt
+            model._programs.clear()
+            torch.cuda.empty_cache()
+        model.set_compute_dtype(torch.bfloat16)
+        dm = DiffusionManager(1e-4, 0.05, 4, device="cuda")
+        dm.seed = 77
+        full = dm.diffusionBackward(xg, cg, ng, model)
+        h = B // 2
+        lo = dm.diffusionBackward(xg[:h], cg[:h], ng[:h], model, first_sample=0)
+        hi = dm.diffusionBackward(xg[h:], cg[h:], ng[h:], model, first_sample=h)
+        assert torch.isfinite(full).all() and torch.equal(torch.cat([lo, hi]), full)
+    finally:
+        model._programs.clear()
+        torch.cuda.empty_cache()
+        model.set_compute_dtype(torch.float32)
+
+
+def test_c3_ddim_shard_size_properties(model):
+    """BASELINE config C3 (DDIM, 50 evenly spaced steps of the T=500 table, B=65536 over 1/2/4/8 GPUs): one 4-GPU rank's share
+    (B=16384), a few steps, bf16: finite, deterministic, and equal bit for bit to the same trajectories sampled as two
+    half-size shards (DDIM with eta=0 draws no noise, so shard invariance is exactly forward invariance)."""
+    from trajectorydiffusion_amd import DiffusionManager
+    B, L = 16384, 200
+    x, _, cat, num = synth_inputs(B, L, T_MODEL, seed=12)
+    xg, cg, ng = x.cuda(), cat.cuda(), num.cuda()
+    dm = DiffusionManager(1e-4, 0.05, T_MODEL, device="cuda")
+    model.set_compute_dtype(torch.bfloat16)
+    try:
+        full = dm.ddimBackward(xg, cg, ng, model, n_steps=3)
+        assert torch.isfinite(full).all()
+        assert torch.equal(dm.ddimBackward(xg, cg, ng, model, n_steps=3), full)
+        h = B // 2
+        parts = [dm.ddimBackward(xg[a:a + h], cg[a:a + h], ng[a:a + h], model, n_steps=3) for a in (0, h)]
+        assert torch.equal(torch.cat(parts), full)
+    finally:
+        model._programs.clear()
+        torch.cuda.empty_cache()
+        model.set_compute_dtype(torch.float32)

@@ -115,3 +115,16 @@ def test_two_process_shard_and_gather_equals_unsharded(tmp_path):
                         "--master-port", "29571", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_persistent_conv_kernels_have_no_spills_in_their_k_loops():
+    """Build check (cross-compiles conv_gemm.hip for gfx950, no GPU needed): a spill reload inside a K loop is a vector-memory
+    operation whose wait also waits for every LDS-DMA in flight, which would serialise the software pipeline."""
+    import shutil
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_spills.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr

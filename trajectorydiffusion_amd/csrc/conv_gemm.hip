@@ -1087,11 +1087,7 @@ struct Epi {
           for (int j = 0; j < VEC; ++j) v[j] += rv[j];
         }
         const uint32_t voff = live ? (uint32_t)(row_local * p.out_ld + q * PC + c * VEC) * ES : kOob;
-#ifdef TDX_EXP_NOSTORE
-        { u32x4 pk = Elem<T>::pack(v); asm volatile("" ::"v"(pk), "v"(voff)); }
-#else
         buf_store16(Elem<T>::pack(v), voff, rsrc_o);
-#endif
       }
       cur = nxt;
     }
@@ -1339,25 +1335,19 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
     else wait_vm(cp_tap == 0 ? 0 : pend_w);  // (a block's first step needs its window)
     counted = false;
-#ifndef TDX_EXP_NOBAR
     __syncthreads();
-#endif
     const int g_now = g, blk_now = blk, tap_now = cp_tap;
     pend_w = 0;
     compute(g & 1, blk & 1, [&]() {
       if constexpr (!LAST) {
-#ifndef TDX_EXP_NOA
         issue_a((g_now + 1) & 1);
-#endif
         if constexpr (!WIN) issue_b_gather((g_now + 1) & 1);
       }
       if constexpr (WIN) {
-#ifndef TDX_EXP_NOW
         if (tap_now == 0 && ld_seg < p.nseg) {
           issue_window((blk_now + 1) & 1);
           pend_w = win_dmas;
         }
-#endif
       }
       // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
       if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
@@ -1409,22 +1399,8 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       patch = scr_a + wave * Cfg::PATCH;
       eb = scr_a + NW * Cfg::PATCH;
     }
-#ifdef TDX_EXP_NOEPI
-    {
-      float t = 0.f;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
-      if (t == 123.456f) p.out[cp_n0] = 1;
-      (void)patch; (void)eb;
-    }
-#else
     epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
-#ifndef TDX_EXP_NOSTORE
     counted = true;
-#endif
-#endif
     if (!more) break;
     jt = jn;
     cp_n0 = nx_n0;

@@ -892,9 +892,11 @@ struct StreamCfg {
 //   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
 //     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
 //     residual of 256-channel tiles (no registers to hold it during the K loop).
-template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_RES, bool RES, bool EB>
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_ROWS, bool PRE_RES, bool RES, bool EB>
 struct Epi {
-  static constexpr bool PRE = PRE_RES;  // 256-channel tiles: no register room in the K loop, everything is read in finish()
+  // PRE_ROWS: the rows that get staged in LDS are read with the tile's first K-step (else in finish()); PRE_RES: so is the
+  // residual.  Both are a question of register room in the K loop (scripts/check_spills.py).
+  static constexpr bool PRE = PRE_ROWS;
   static constexpr int ES = (int)sizeof(T);
   static constexpr int VEC = 16 / ES;
   static constexpr int PC = 32, NQ = WCO / PC;  // channels per transposed piece, pieces per sub-tile row
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   int jt = blockIdx.x >> 3, cp_n0, cp_co0;
   if (!tile_of(jt, cp_n0, cp_co0)) return;
 
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128, RES, EB>;
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128 || WIN, TC == 128, RES, EB>;
   // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
   int ld_n0 = 0;
   u32x4 rsrc_a, rsrc_b;

@@ -166,6 +166,41 @@ int tdx_didi_items(const float* lon_lat_raw, const float* minutes, const float* 
 /* Inverse z-score (not in the reference): lon_lat (B, 2, L) -> degrees (B, L, 2). */
 int tdx_didi_denorm(const float* lon_lat, const float* stats, float* out_deg, int32_t B, int32_t L, void* stream);
 
+/* ---- Training-step building blocks (train.ipynb:198-209).  fp32 arithmetic; every reduction has a
+ * fixed order (two stages through a caller-provided workspace, no atomics).  The step itself is not assembled yet. ---- */
+
+/* Floats a workspace `ws` must hold for tdx_mse_loss_grad and tdx_colsum. */
+int64_t tdx_train_workspace_floats(void);
+
+/* torch.nn.MSELoss()(pred, target) and its gradient (train.ipynb:205-206): *loss = mean((pred - target)^2),
+ * dpred[i] = 2 (pred[i] - target[i]) / n (dpred may be null). */
+int tdx_mse_loss_grad(const float* pred, const float* target, float* dpred, float* loss, int64_t n, float* ws, void* stream);
+
+/* out[c] (+)= sum over the n rows of x[r * ld + c], c < C <= 4096: bias gradients of Conv1d / Linear, and dgamma / dbeta from the
+ * per-trajectory rows of tdx_groupnorm_act_bwd. */
+int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int32_t accumulate, int32_t dtype, float* ws, void* stream);
+
+/* Weight gradient of one K-segment of tdx_conv_gemm (autograd of nn.Conv1d, TrajUNetBlocks.py:77,86,89):
+ *   dw[co][ci_off + ci][t] (+)= sum over output rows n of dy[n * dy_ld + dy_off + co] * X[src(n, t)][ci],
+ * dw in the reference layout (Cout, cin_total, taps) fp32, src(n, t) = the forward row map of `seg` (padding, stride 2,
+ * nearest-upsampled source).  ws holds splits * cout * cin * taps floats (splits <= 64, chosen to fit ws_floats). */
+int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
+                   float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
+                   void* stream);
+
+/* Backward of tdx_groupnorm_act (nn.GroupNorm + Swish, TrajUNetBlocks.py:75-76,83-84): from the forward INPUT x and the
+ * gradient dy of the activated output, dx (+)= gradient of x; dgamma_rows / dbeta_rows (B, C) fp32 receive each
+ * trajectory's share of the parameter gradients (sum them with tdx_colsum). */
+int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                          int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
+                          int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
+                          void* stream);
+
+/* torch.optim.AdamW single-tensor update (train.ipynb:131: lr 5e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01);
+ * step counts from 1.  Hyper-parameters are doubles, as torch keeps them: 1 - beta2 must be formed before rounding to fp32. */
+int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

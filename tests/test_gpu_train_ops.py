@@ -1,0 +1,184 @@
+"""GPU: training-step building blocks through the C ABI against torch autograd / torch.optim on the CPU."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _eng():
+    from trajectorydiffusion_amd import _lib, engine
+    return engine, _lib
+
+
+def q(x, dt):
+    return x.to(dt).float()
+
+
+def rows(x, dt):  # (B, C, L) -> channels-last rows (B, L, C) on the GPU
+    return x.permute(0, 2, 1).contiguous().to("cuda", dt)
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def workspace(n=None):
+    _, _lib = _eng()
+    return torch.empty(int(n or _lib.lib().tdx_train_workspace_floats()), device="cuda", dtype=torch.float32)
+
+
+def test_mse_loss_and_gradient():
+    _, _lib = _eng()
+    g = torch.Generator().manual_seed(0)
+    for n in (5, 1600, 2 * 200 * 1024):
+        pred, tgt = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        p = pred.clone().requires_grad_(True)
+        loss = F.mse_loss(p, tgt)
+        loss.backward()
+        pd, td = pred.cuda(), tgt.cuda()
+        dp, lo, ws = torch.empty_like(pd), torch.zeros(1, device="cuda"), workspace()
+        _lib.check(_lib.lib().tdx_mse_loss_grad(pd.data_ptr(), td.data_ptr(), dp.data_ptr(), lo.data_ptr(), n, ws.data_ptr(), _lib.stream_ptr()))
+        assert abs(float(lo) - float(loss.detach())) < 2e-6 * float(loss.detach())
+        assert rel(dp.cpu(), p.grad) < 1e-6
+        lo2 = torch.zeros(1, device="cuda")
+        _lib.check(_lib.lib().tdx_mse_loss_grad(pd.data_ptr(), td.data_ptr(), dp.data_ptr(), lo2.data_ptr(), n, ws.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(lo, lo2)  # fixed-order reduction
+
+
+def test_adamw_matches_torch_optim():
+    _, _lib = _eng()
+    g = torch.Generator().manual_seed(1)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)   # train.ipynb:131
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (0.1 if step % 2 else 3.0)
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        _lib.check(_lib.lib().tdx_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 5e-4, 0.9, 0.999, 1e-8, 0.01, step,
+                                             _lib.stream_ptr()))
+        assert rel(p.cpu(), ref.detach()) < 1e-6, step
+    st = opt.state[ref]
+    assert rel(m.cpu(), st["exp_avg"]) < 1e-6 and rel(v.cpu(), st["exp_avg_sq"]) < 1e-6
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n,c", [(1, 8), (300, 128), (33431, 384), (4096 * 13, 1024)])
+def test_colsum(dt, n, c):
+    _, _lib = _eng()
+    x = torch.randn(n, c + 8, generator=torch.Generator().manual_seed(n))
+    xd = x.to("cuda", dt)
+    out, ws = torch.full((c,), 7.0, device="cuda"), workspace()
+    for acc in (0, 1):
+        _lib.check(_lib.lib().tdx_colsum(xd.data_ptr() + 8 * xd.element_size(), c + 8, n, c, out.data_ptr(), acc, _lib.dtype_code(dt),
+                                         ws.data_ptr(), _lib.stream_ptr()))
+        ref = (acc + 1) * q(x, dt)[:, 8:].double().sum(0).float()
+        assert rel(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", ["k3", "k3_s2", "k3_up", "k1", "concat_half", "ragged"])
+def test_conv_weight_gradient(dt, case):
+    """dW of nn.Conv1d from autograd, for every source map the forward conv supports."""
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(len(case))
+    B, L, Ci, Co, k, stride, up, ci_off, cin_total = 37, 50, 128, 192, 3, 1, None, 0, None
+    if case == "k3_s2":
+        stride = 2
+    elif case == "k3_up":
+        L, up = 25, 50
+    elif case == "k1":
+        k = 1
+    elif case == "concat_half":
+        ci_off, cin_total = 64, 128 + 64 + 32   # this source is channels 64..191 of a wider (concatenated) conv input
+    elif case == "ragged":
+        B, L, Ci, Co = 5, 13, 40, 72
+    cin_total = cin_total or Ci
+    x = torch.randn(B, Ci, L, generator=g)
+    xq = q(x, dt)
+    xin = F.interpolate(xq, size=up, mode="nearest") if up else xq
+    w = torch.randn(Co, Ci, k, generator=g, requires_grad=True)
+    y = F.conv1d(xin, w, stride=stride, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    dyq = q(dy, dt)
+    y.backward(dyq)
+    lout = y.shape[2]
+    src, dyr = rows(x, dt), rows(dy, dt)
+    seg = _lib.KSeg(src.data_ptr(), float(L) / up if up else 0.0, 0, Ci, 0, Ci, k, stride, L, up or L, 0)
+    dw = torch.full((Co, cin_total, k), 0.5, device="cuda")
+    ws = workspace(64 * Co * Ci * k)
+    for acc in (0, 1):
+        _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, dw.data_ptr(), cin_total, ci_off, acc,
+                                             _lib.dtype_code(dt), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        got = dw.cpu()[:, ci_off:ci_off + Ci, :]
+        assert rel(got, (acc + 1) * w.grad) < 2e-5, acc
+    untouched = torch.ones(cin_total, dtype=torch.bool)
+    untouched[ci_off:ci_off + Ci] = False
+    assert bool((dw.cpu()[:, untouched, :] == 0.5).all())
+    small = workspace(Co * Ci * k)   # room for a single slab: still correct
+    _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, dw.data_ptr(), cin_total, ci_off, 0,
+                                         _lib.dtype_code(dt), small.data_ptr(), small.numel(), _lib.stream_ptr()))
+    assert rel(dw.cpu()[:, ci_off:ci_off + Ci, :], w.grad) < 2e-5
+    with pytest.raises(_lib.TdxError):
+        _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, dw.data_ptr(), cin_total, ci_off, 0,
+                                             _lib.dtype_code(dt), small.data_ptr(), 16, _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_data_gradient_is_the_forward_kernel_on_flipped_weights(dt, k):
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(k)
+    B, L, Ci, Co = 130, 25, 128, 256
+    x = torch.randn(B, Ci, L, generator=g, requires_grad=True)
+    w = torch.randn(Co, Ci, k, generator=g) / (k * Ci) ** 0.5
+    y = F.conv1d(x, q(w, dt), padding=k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dt))
+    pg = engine.Program(torch.device("cuda"), dt)
+    dx = torch.empty((B, L, Ci), device="cuda", dtype=dt)
+    pg.conv([engine.Seg(rows(dy, dt), Co, Co, L, taps=k)], engine.pack_conv_weight_dgrad(w.cuda(), dt), None, dx, Ci, B, L, Ci)
+    pg.run()
+    torch.cuda.synchronize()
+    got = dx.float().cpu().permute(0, 2, 1)
+    assert rel(got, x.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,L,C,act", [(3, 200, 128, 2), (2, 25, 1024, 2), (5, 13, 256, 0), (2, 7, 2048, 2)])
+def test_groupnorm_swish_backward(dt, B, L, C, act):
+    _, _lib = _eng()
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, C, L, generator=g) * 2 + 0.3
+    xq = q(x, dt).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    u = F.group_norm(xq, 32, gamma, beta, 1e-5)
+    y = u * torch.sigmoid(u) if act == 2 else u
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dt))
+    xr, dyr = rows(x, dt), rows(dy, dt)
+    dx = torch.zeros((B, L, C + 16), device="cuda", dtype=dt)
+    dgr, dbr = torch.empty((B, C), device="cuda"), torch.empty((B, C), device="cuda")
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    for acc in (0, 1):
+        _lib.check(_lib.lib().tdx_groupnorm_act_bwd(xr.data_ptr(), C, dyr.data_ptr(), C, 0, dx.data_ptr(), C + 16, 16, gd.data_ptr(), bd.data_ptr(),
+                                                    dgr.data_ptr(), dbr.data_ptr(), B, L, C, 32, 1e-5, act, acc, _lib.dtype_code(dt), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got = dx.float().cpu()[:, :, 16:].permute(0, 2, 1)
+        assert rel(got, (acc + 1) * xq.grad) < tol, acc
+    assert float(dx[:, :, :16].abs().max()) == 0.0
+    ws = workspace()
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    for src, dst in ((dgr, dgam), (dbr, dbet)):
+        _lib.check(_lib.lib().tdx_colsum(src.data_ptr(), C, B, C, dst.data_ptr(), 0, _lib.TDX_F32, ws.data_ptr(), _lib.stream_ptr()))
+    assert rel(dgam.cpu(), gamma.grad) < 5e-5 and rel(dbet.cpu(), beta.grad) < 5e-5

@@ -51,6 +51,13 @@ _SIGNATURES = {
     "tdx_q_sample": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "tdx_didi_items": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "tdx_didi_denorm": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "tdx_train_workspace_floats": (_i64, []),
+    "tdx_mse_loss_grad": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tdx_colsum": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
+                                     _i32, _i32, _vp]),
+    "tdx_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,411 @@
+// Training-step building blocks (train.ipynb:198-209): eps-MSE loss and its gradient, column sums
+// (bias gradients), convolution weight gradients, GroupNorm(+Swish) backward, fused AdamW.  fp32 arithmetic throughout;
+// every reduction has a fixed order (two stages through a caller-provided workspace, no atomics): results are bitwise
+// reproducible.  The step itself (saved activations, backward program, DDP all-reduce) is not assembled yet.
+#include "tdx_common.h"
+
+namespace {
+
+constexpr int kRedBlocks = 1024;  // first-stage partials of the scalar / column reductions
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {  // fixed-order tree: lanes, then the four waves
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// ---- loss = mean((pred - target)^2), dpred = 2 (pred - target) / n  (torch.nn.MSELoss, train.ipynb:205) ----------------
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         float* __restrict__ dpred, float* __restrict__ part, long n, float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = pred[i] - target[i];
+    acc += d * d;
+    if (dpred) dpred[i] = d * scale;
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out, float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+// ---- column sums of a row-major (n, c) matrix: bias gradients, GroupNorm dgamma / dbeta ------------------------------------
+// stage 1: block (row slab, 64-column window) -> part[slab][c]; stage 2: fixed-order sum over slabs.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int ld, int n, int c, float* __restrict__ part, int slabs) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int per = (n + slabs - 1) / slabs;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  float acc = 0.f;
+  if (col < c)
+    for (int r = r0 + sub; r < r1; r += 4) acc += Elem<T>::ld(x + (size_t)r * ld + col);
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && col < c) part[(size_t)blockIdx.x * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int slabs, int c, float* __restrict__ out, int accumulate) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  float acc = 0.f;
+  for (int s = 0; s < slabs; ++s) acc += part[(size_t)s * c + col];
+  out[col] = accumulate ? out[col] + acc : acc;
+}
+
+// ---- AdamW, one fused pass (torch.optim.AdamW single-tensor semantics, train.ipynb:131) --------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float omb1, float beta2, float omb2, float eps,
+                                                   float decay, float step_size, float bc2_sqrt) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * decay;                            // param.mul_(1 - lr * weight_decay)
+  const float mi = m[i] + (gi - m[i]) * omb1;  // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = v[i] * beta2 + omb2 * gi * gi;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;     // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+  pi -= step_size * (mi / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+  p[i] = pi;
+  m[i] = mi;
+  v[i] = vi;
+}
+
+
+// ---- convolution weight gradient -----------------------------------------------------------------------------------------
+// dW[co][ci][t] = sum over output rows n of dY[n][co] * X[src(n, t)][ci], src = the same row map as the forward gather (zero
+// padding, stride 2, nearest-upsampled source: tdx_kseg).  A GEMM whose reduction runs over the B * lout rows: the grid splits
+// the rows into `splits` slabs (partials in the workspace), a second kernel adds the slabs in fixed order.
+// Tile: 64 co x 64 ci of one tap; 32 rows per LDS stage, converted to fp32; v_mfma_f32_16x16x4f32 with A = dY^T, B = X.
+struct WgradArgs {
+  const char* dy;
+  const char* x;
+  int32_t dy_ld, dy_off, cout;
+  int32_t x_ld, x_off, cin, taps, stride, lin, lvirt;
+  float up_scale;
+  int32_t N, lout, rows_per_split;
+  float* part;  // [splits][cout][cin * taps]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RC = 32, LDS_LD = 80;  // row stride 80 floats: the four k rows of an MFMA operand fall on disjoint banks
+  __shared__ float dys[RC * LDS_LD], xs[RC * LDS_LD];
+  const int co0 = blockIdx.x * 64;
+  const int ci_tiles = (p.cin + 63) / 64;
+  const int tap = blockIdx.y / ci_tiles, ci0 = (blockIdx.y % ci_tiles) * 64;
+  const int split = blockIdx.z;
+  const int r_begin = split * p.rows_per_split, r_end = min(p.N, r_begin + p.rows_per_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = tid >> 3, c8 = (tid & 7) * 8;  // loader role: row lr of the chunk, 8 consecutive channels
+  const int pad = p.taps == 3 ? 1 : 0;
+  const T* dy = reinterpret_cast<const T*>(p.dy);
+  const T* x = reinterpret_cast<const T*>(p.x);
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r0 = r_begin; r0 < r_end; r0 += RC) {
+    const int n = r0 + lr;
+    const bool row_ok = n < r_end;
+    const int b = row_ok ? n / p.lout : 0, l = row_ok ? n - b * p.lout : 0;
+    const int u = l * p.stride + tap - pad;
+    const bool src_ok = row_ok && u >= 0 && u < p.lvirt;
+    const int uu = src_ok ? u : 0;
+    const int srow = p.up_scale > 0.f ? min((int)floorf((float)uu * p.up_scale), p.lin - 1) : uu;
+    const T* dyr = dy + (size_t)n * p.dy_ld + p.dy_off + co0 + c8;
+    const T* xr = x + ((size_t)b * p.lin + srow) * p.x_ld + p.x_off + ci0 + c8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dys[lr * LDS_LD + c8 + j] = (row_ok && co0 + c8 + j < p.cout) ? Elem<T>::ld(dyr + j) : 0.f;
+      xs[lr * LDS_LD + c8 + j] = (src_ok && ci0 + c8 + j < p.cin) ? Elem<T>::ld(xr + j) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k4 = 0; k4 < RC / 4; ++k4) {
+      const int kr = k4 * 4 + (lane >> 4);
+      const float a = dys[kr * LDS_LD + wave * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[kr * LDS_LD + j * 16 + (lane & 15)], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[j][r] = dW[co0 + 16 * wave + 4 * (lane >> 4) + r][ci0 + 16 * j + (lane & 15)]
+  const int kdim = p.cin * p.taps;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = ci0 + j * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wave * 16 + 4 * (lane >> 4) + r;
+      if (co < p.cout && ci < p.cin) p.part[((size_t)split * p.cout + co) * kdim + ci * p.taps + tap] = acc[j][r];
+    }
+  }
+#endif
+}
+
+// dw[co][ci_off + ci][t] (row length cin_total * taps) = (accumulate ? dw : 0) + sum over splits, in split order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int cout, int cin, int taps,
+                                                          float* __restrict__ dw, int cin_total, int ci_off, int accumulate) {
+  const long kdim = (long)cin * taps, total = (long)cout * kdim;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long co = i / kdim, k = i - co * kdim;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += part[(size_t)s * total + i];
+  float* o = dw + ((size_t)co * cin_total + ci_off) * taps + k;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// ---- GroupNorm (+ Swish) backward ------------------------------------------------------------------------------------------
+// forward: xh = (x - mean_g) * rstd_g ; u = xh * gamma + beta ; y = act(u).
+// backward: du = dy * act'(u) ; dgamma_c = sum du * xh ; dbeta_c = sum du ; dxh = du * gamma ;
+//           dx = rstd_g * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh)).
+// One wave per (trajectory, channel window), same decomposition as the forward kernel; four sweeps over the rows (statistics
+// are recomputed, nothing but x was saved by the forward pass).  Per-channel sums are written per trajectory
+// (dgamma_rows / dbeta_rows, (B, C) fp32); tdx_colsum over those rows gives dgamma / dbeta in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+                                                               int dy_off, T* __restrict__ dx, int dx_ld, int dx_off,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ dgamma_rows, float* __restrict__ dbeta_rows, int B,
+                                                               int L, int C, int cpg, int lpr, float eps, int act, int accumulate) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int H = VEC / 2;
+  const int lane = threadIdx.x & 63;
+  const int W = lpr * VEC;
+  const int wins = C / W;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long)B * wins) return;  // wave-uniform
+  const int b = (int)(wid / wins), win = (int)(wid % wins);
+  const int col = lane % lpr, rl = lane / lpr, rpi = 64 / lpr;
+  const int ch = win * W + col * VEC;
+  const T* xb = x + ((size_t)b * L) * x_ld + ch;
+  const T* dyb = dy + ((size_t)b * L) * dy_ld + dy_off + ch;
+  T* dxb = dx + ((size_t)b * L) * dx_ld + dx_off + ch;
+  const bool split = cpg < VEC;
+  auto group_sum = [&](float& lo, float& hi) {
+    for (int o = 32; o >= lpr; o >>= 1) {
+      lo += __shfl_xor(lo, o, 64);
+      hi += __shfl_xor(hi, o, 64);
+    }
+    if (!split) {
+      lo += hi;
+      for (int o = 1; o * VEC < cpg; o <<= 1) lo += __shfl_xor(lo, o, 64);
+      hi = lo;
+    }
+  };
+  auto rowv = [&](const T* base, int ld, int l, float (&v)[VEC]) { Elem<T>::unpack(*reinterpret_cast<const u32x4*>(base + (size_t)l * ld), v); };
+  const float inv_cnt = 1.0f / ((float)cpg * (float)L);
+  float s_lo = 0.f, s_hi = 0.f;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC];
+    rowv(xb, x_ld, l, v);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      s_lo += v[j];
+      s_hi += v[H + j];
+    }
+  }
+  group_sum(s_lo, s_hi);
+  const float m_lo = s_lo * inv_cnt, m_hi = s_hi * inv_cnt;
+  float q_lo = 0.f, q_hi = 0.f;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC];
+    rowv(xb, x_ld, l, v);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const float a = v[j] - m_lo, c = v[H + j] - m_hi;
+      q_lo += a * a;
+      q_hi += c * c;
+    }
+  }
+  group_sum(q_lo, q_hi);
+  const float r_lo = rsqrtf(q_lo * inv_cnt + eps), r_hi = rsqrtf(q_hi * inv_cnt + eps);
+  float gm[VEC], bt[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    gm[j] = gamma[ch + j];
+    bt[j] = beta[ch + j];
+  }
+  // du and the four sums
+  auto du_of = [&](float xh, float dyv, int j) {
+    const float u = xh * gm[j] + bt[j];
+    if (act == TDX_ACT_SWISH) {
+      const float sg = 1.0f / (1.0f + __expf(-u));
+      return dyv * (sg * (1.0f + u * (1.0f - sg)));
+    }
+    if (act == TDX_ACT_LEAKY) return u > 0.f ? dyv : 0.1f * dyv;
+    return dyv;
+  };
+  float a_lo = 0.f, a_hi = 0.f, c_lo = 0.f, c_hi = 0.f;  // group sums of dxh and dxh * xh
+  float dg[VEC], db[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) dg[j] = db[j] = 0.f;
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC], g[VEC];
+    rowv(xb, x_ld, l, v);
+    rowv(dyb, dy_ld, l, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float xh = (v[j] - (j < H ? m_lo : m_hi)) * (j < H ? r_lo : r_hi);
+      const float du = du_of(xh, g[j], j);
+      dg[j] += du * xh;
+      db[j] += du;
+      const float dxh = du * gm[j];
+      if (j < H) {
+        a_lo += dxh;
+        c_lo += dxh * xh;
+      } else {
+        a_hi += dxh;
+        c_hi += dxh * xh;
+      }
+    }
+  }
+  group_sum(a_lo, a_hi);
+  group_sum(c_lo, c_hi);
+  const float ma_lo = a_lo * inv_cnt, ma_hi = a_hi * inv_cnt, mc_lo = c_lo * inv_cnt, mc_hi = c_hi * inv_cnt;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j)
+    for (int o = 32; o >= lpr; o >>= 1) {
+      dg[j] += __shfl_xor(dg[j], o, 64);
+      db[j] += __shfl_xor(db[j], o, 64);
+    }
+  if (rl == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      dgamma_rows[(size_t)b * C + ch + j] = dg[j];
+      dbeta_rows[(size_t)b * C + ch + j] = db[j];
+    }
+  }
+  for (int l = rl; l < L; l += rpi) {
+    float v[VEC], g[VEC], o[VEC];
+    rowv(xb, x_ld, l, v);
+    rowv(dyb, dy_ld, l, g);
+    if (accumulate) rowv(dxb, dx_ld, l, o);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float r = j < H ? r_lo : r_hi;
+      const float xh = (v[j] - (j < H ? m_lo : m_hi)) * r;
+      const float dxh = du_of(xh, g[j], j) * gm[j];
+      const float d = r * (dxh - (j < H ? ma_lo : ma_hi) - xh * (j < H ? mc_lo : mc_hi));
+      o[j] = accumulate ? o[j] + d : d;
+    }
+    *reinterpret_cast<u32x4*>(dxb + (size_t)l * dx_ld) = Elem<T>::pack(o);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t tdx_train_workspace_floats(void) { return (int64_t)kRedBlocks * 4096; }
+
+extern "C" int tdx_mse_loss_grad(const float* pred, const float* target, float* dpred, float* loss, int64_t n, float* ws, void* stream) {
+  TDX_CHECK_ARG(pred && target && loss && ws && n > 0, "tdx_mse_loss_grad: null pointer or empty input");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, ws, (long)n, 2.0f / (float)n);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, blocks, loss, 1.0f / (float)n);
+  TDX_CHECK_LAUNCH("mse_loss_grad");
+  return TDX_OK;
+}
+
+extern "C" int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int32_t accumulate, int32_t dtype, float* ws, void* stream) {
+  TDX_CHECK_ARG(x && out && ws && n > 0 && c > 0 && ld >= c, "tdx_colsum: bad arguments n=%d c=%d ld=%d", n, c, ld);
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_colsum: bad dtype %d", dtype);
+  TDX_CHECK_ARG(c <= 4096, "tdx_colsum: c=%d exceeds the workspace (4096 columns)", c);
+  hipStream_t st = (hipStream_t)stream;
+  int slabs = (n + 255) / 256;
+  if (slabs > kRedBlocks) slabs = kRedBlocks;
+  const dim3 grid((unsigned)slabs, (unsigned)((c + 63) / 64));
+  if (dtype == TDX_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, n, c, ws, slabs);
+  else hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, ld, n, c, ws, slabs);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
+  TDX_CHECK_LAUNCH("colsum");
+  return TDX_OK;
+}
+
+extern "C" int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int32_t step, void* stream) {
+  TDX_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "tdx_adamw_step: null pointer or empty tensor");
+  TDX_CHECK_ARG(step >= 1, "tdx_adamw_step: step=%d (1-based)", step);
+  // scalar bookkeeping in double, as torch does it in Python floats
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float decay = (float)(1.0 - lr * weight_decay), step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay, step_size, bc2_sqrt);
+  TDX_CHECK_LAUNCH("adamw_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
+                              float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
+                              void* stream) {
+  TDX_CHECK_ARG(dy && seg && seg->src && dw && ws, "tdx_conv_wgrad: null pointer");
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_conv_wgrad: bad dtype %d", dtype);
+  TDX_CHECK_ARG(B > 0 && lout > 0 && cout > 0 && dy_off >= 0 && dy_off + cout <= dy_ld, "tdx_conv_wgrad: bad dY shape");
+  TDX_CHECK_ARG((int64_t)B * lout < (1ll << 31), "tdx_conv_wgrad: B*lout overflows int32");
+  const tdx_kseg& s = *seg;
+  TDX_CHECK_ARG(s.taps == 1 || s.taps == 3, "tdx_conv_wgrad: taps=%d (1 or 3)", s.taps);
+  TDX_CHECK_ARG(s.stride == 1 || s.stride == 2, "tdx_conv_wgrad: stride=%d (1 or 2)", s.stride);
+  TDX_CHECK_ARG(s.cin > 0 && s.ch_off >= 0 && s.ch_off + s.cin <= s.src_ld && s.lin > 0 && s.lvirt > 0, "tdx_conv_wgrad: bad source shape");
+  TDX_CHECK_ARG(s.lvirt == s.lin || s.up_scale > 0.f, "tdx_conv_wgrad: lvirt != lin needs up_scale = (float)lin / lvirt");
+  const int pad = s.taps == 3 ? 1 : 0;
+  TDX_CHECK_ARG((s.lvirt + 2 * pad - s.taps) / s.stride + 1 == lout, "tdx_conv_wgrad: source yields a different number of output rows than lout=%d", lout);
+  TDX_CHECK_ARG(ci_off >= 0 && ci_off + s.cin <= cin_total, "tdx_conv_wgrad: ci_off/cin_total do not fit");
+  const int N = B * lout;
+  const int64_t per_split = (int64_t)cout * s.cin * s.taps;
+  int splits = (N + 2047) / 2048;
+  if (splits > 64) splits = 64;
+  if ((int64_t)splits * per_split > ws_floats) splits = (int)(ws_floats / per_split);
+  TDX_CHECK_ARG(splits >= 1, "tdx_conv_wgrad: workspace of %lld floats is smaller than one gradient (%lld)", (long long)ws_floats, (long long)per_split);
+  WgradArgs a{(const char*)dy, (const char*)s.src, dy_ld, dy_off, cout, s.src_ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt,
+              s.lvirt != s.lin ? s.up_scale : 0.f, N, lout, ((N + splits - 1) / splits + 31) / 32 * 32, ws};
+  splits = (N + a.rows_per_split - 1) / a.rows_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)(((s.cin + 63) / 64) * s.taps), (unsigned)splits);
+  if (dtype == TDX_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, st, ws, splits, cout, s.cin, s.taps, dw,
+                     cin_total, ci_off, accumulate);
+  TDX_CHECK_LAUNCH("conv_wgrad");
+  return TDX_OK;
+}
+
+extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                                     int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
+                                     int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
+                                     void* stream) {
+  TDX_CHECK_ARG(x && dy && dx && gamma && beta && dgamma_rows && dbeta_rows, "tdx_groupnorm_act_bwd: null pointer");
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_groupnorm_act_bwd: bad dtype %d", dtype);
+  TDX_CHECK_ARG(B > 0 && L > 0 && C > 0 && groups > 0 && C % groups == 0, "tdx_groupnorm_act_bwd: bad shape B=%d L=%d C=%d groups=%d", B, L, C, groups);
+  TDX_CHECK_ARG(act == TDX_ACT_NONE || act == TDX_ACT_SWISH || act == TDX_ACT_LEAKY, "tdx_groupnorm_act_bwd: bad act %d", act);
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  const int cpg = C / groups;
+  if (cpg < 4 || (cpg & (cpg - 1)) != 0 || cpg < vec / 2)
+    TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act_bwd: channels per group = %d; need a power of two >= %d", cpg, vec / 2 > 4 ? vec / 2 : 4);
+  int lpr = 8;
+  while (lpr * vec < cpg) lpr <<= 1;
+  if (lpr > 64 || C % (lpr * vec) != 0)
+    TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act_bwd: C=%d not a multiple of the %d-channel window", C, lpr * vec);
+  TDX_CHECK_ARG(x_ld % vec == 0 && dy_ld % vec == 0 && dy_off % vec == 0 && dx_ld % vec == 0 && dx_off % vec == 0 && x_ld >= C &&
+                    dy_off + C <= dy_ld && dx_off + C <= dx_ld,
+                "tdx_groupnorm_act_bwd: leading dimensions / offsets must be multiples of %d and fit", vec);
+  const long waves = (long)B * (C / (lpr * vec));
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TDX_F32)
+    hipLaunchKernelGGL(groupnorm_act_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, x_ld, (const float*)dy, dy_ld, dy_off,
+                       (float*)dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate);
+  else
+    hipLaunchKernelGGL(groupnorm_act_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, x_ld, (const __bf16*)dy, dy_ld, dy_off,
+                       (__bf16*)dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate);
+  TDX_CHECK_LAUNCH("groupnorm_act_bwd_kernel");
+  return TDX_OK;
+}

@@ -49,6 +49,14 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return torch.cat(blocks, dim=1).to(dtype).contiguous()
 
 
+def pack_conv_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Weights of the data-gradient conv of a stride-1 Conv1d (training step).
+
+    y[l] = sum_t W[:, :, t] x[l + t - pad]  =>  dx[u] = sum_t' W[:, :, k-1-t']^T dy[u + t' - pad]: the same gathered GEMM
+    (tdx_conv_gemm) run on dy with the taps flipped and the channel roles exchanged."""
+    return pack_conv_weight(w.detach().flip(2).transpose(0, 1).contiguous(), dtype)
+
+
 class Seg:
     """One K-segment of a gathered GEMM (see tdx_kseg in include/trajdiff_hip.h)."""
     __slots__ = ("src", "ld", "ch_off", "cin", "taps", "stride", "lin", "lvirt")

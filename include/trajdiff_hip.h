@@ -196,6 +196,18 @@ int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t d
                           int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
                           void* stream);
 
+/* Data gradient of a STRIDE-1 Conv1d: tdx_conv_gemm on dy with the weights of engine.pack_conv_weight_dgrad (taps flipped, channel
+ * roles exchanged).  Stride 2 (TrajUNet.py:44): the even input rows see only the centre tap (a k=1 conv of dy with W[:,:,1]^T), the
+ * odd rows the two outer taps (a k=3 conv of dy with taps {0, W[:,:,2]^T, W[:,:,0]^T}); both phase tensors are (B, ceil(L/2), C),
+ * and tdx_interleave2 merges them: out[b][u] (+)= u even ? even[b][u/2] : odd[b][u/2], u < L (engine.conv_dgrad_stride2). */
+int tdx_interleave2(const void* even, const void* odd, void* out, int32_t out_ld, int32_t out_off, int32_t B, int32_t L, int32_t C,
+                    int32_t accumulate, int32_t dtype, void* stream);
+
+/* Data gradient through F.interpolate(mode='nearest', size=lvirt) (TrajUNet.py:93): dx[b][s] (+)= sum of du[b][u] over the
+ * virtual rows u with min(floor(u * lin / lvirt), lin - 1) == s. */
+int tdx_upsample_fold(const void* du, int32_t du_ld, int32_t du_off, void* dx, int32_t dx_ld, int32_t dx_off, int32_t B, int32_t lin,
+                      int32_t lvirt, int32_t C, int32_t accumulate, int32_t dtype, void* stream);
+
 /* torch.optim.AdamW single-tensor update (train.ipynb:131: lr 5e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01);
  * step counts from 1.  Hyper-parameters are doubles, as torch keeps them: 1 - beta2 must be formed before rounding to fp32. */
 int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,

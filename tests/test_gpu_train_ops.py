@@ -182,3 +182,45 @@ def test_groupnorm_swish_backward(dt, B, L, C, act):
     for src, dst in ((dgr, dgam), (dbr, dbet)):
         _lib.check(_lib.lib().tdx_colsum(src.data_ptr(), C, B, C, dst.data_ptr(), 0, _lib.TDX_F32, ws.data_ptr(), _lib.stream_ptr()))
     assert rel(dgam.cpu(), gamma.grad) < 5e-5 and rel(dbet.cpu(), beta.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("L", [50, 25, 200])
+def test_conv_data_gradient_stride2(dt, L):
+    """Stride-2 down conv (TrajUNet.py:44): two forward-kernel launches on dy (one per input-row parity) + tdx_interleave2."""
+    engine, _lib = _eng()
+    g = torch.Generator().manual_seed(L)
+    B, Ci, Co = 40, 128, 128
+    x = torch.randn(B, Ci, L, generator=g, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, generator=g) / (3 * Ci) ** 0.5
+    y = F.conv1d(x, q(w, dt), stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dt))
+    we, wo = engine.pack_conv_weight_dgrad_stride2(w.cuda(), dt)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    dx = torch.empty((B, L, Ci), device="cuda", dtype=dt)
+    for acc in (False, True):
+        pg = engine.Program(torch.device("cuda"), dt)
+        engine.conv_dgrad_stride2(pg, rows(dy, dt), we, wo, dx, B, L, Co, Ci, accumulate=acc)
+        pg.run()
+        torch.cuda.synchronize()
+        assert rel(dx.float().cpu().permute(0, 2, 1), (2 if acc else 1) * x.grad) < (tol if not acc else 2 * tol)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("li,lo", [(13, 25), (25, 50), (100, 200), (12, 24), (24, 47), (7, 7)])
+def test_upsample_fold_is_the_gradient_of_nearest_interpolate(dt, li, lo):
+    _, _lib = _eng()
+    g = torch.Generator().manual_seed(li)
+    B, C = 3, 64
+    x = torch.randn(B, C, li, generator=g, requires_grad=True)
+    up = F.interpolate(x, size=lo, mode="nearest")
+    du = torch.randn(up.shape, generator=g)
+    up.backward(q(du, dt))
+    dud = rows(du, dt)
+    dx = torch.zeros((B, li, C + 8), device="cuda", dtype=dt)
+    for acc in (0, 1):
+        _lib.check(_lib.lib().tdx_upsample_fold(dud.data_ptr(), C, 0, dx.data_ptr(), C + 8, 8, B, li, lo, C, acc, _lib.dtype_code(dt), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert rel(dx.float().cpu()[:, :, 8:].permute(0, 2, 1), (acc + 1) * x.grad) < (1e-6 if dt == torch.float32 else 2e-2)
+    assert float(dx[:, :, :8].abs().max()) == 0.0

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
                                      _i32, _i32, _vp]),
+    "tdx_interleave2": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_upsample_fold": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -302,6 +302,63 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
   }
 }
 
+// ---- row re-indexing of data gradients -----------------------------------------------------------------------------------
+// interleave2: out[b][u] (+)= (u even ? even[b][u / 2] : odd[b][u / 2]): the two phases of a stride-2 conv's data gradient
+// (even input rows see only the centre tap, odd rows the two outer taps), each computed by tdx_conv_gemm on dy.
+template <typename T>
+__global__ __launch_bounds__(256) void interleave2_kernel(const T* __restrict__ even, int le, const T* __restrict__ odd,
+                                                         T* __restrict__ out, int out_ld, int out_off, int B, int L, int C, int accumulate) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int vpr = C / VEC;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * L * vpr) return;
+  const int cv = (int)(i % vpr);
+  const long row = i / vpr;
+  const int b = (int)(row / L), u = (int)(row - (long)b * L);
+  const T* src = ((u & 1) ? odd : even) + ((size_t)b * le + (u >> 1)) * C;  // both phase tensors are (B, ceil(L / 2), C)
+  T* dst = out + (size_t)row * out_ld + out_off + cv * VEC;
+  float v[VEC];
+  Elem<T>::unpack(*reinterpret_cast<const u32x4*>(src + cv * VEC), v);
+  if (accumulate) {
+    float o[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] += o[j];
+  }
+  *reinterpret_cast<u32x4*>(dst) = Elem<T>::pack(v);
+}
+
+// upsample_fold: dx[b][s] (+)= sum of du[b][u] over the virtual rows u that F.interpolate(mode='nearest') takes from source
+// row s, i.e. min(floor(u * scale), lin - 1) == s (ATen's index formula, the one the forward gather uses).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fold_kernel(const T* __restrict__ du, int du_ld, int du_off, T* __restrict__ dx, int dx_ld,
+                                                           int dx_off, int B, int lin, int lvirt, int C, float scale, int accumulate) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int vpr = C / VEC;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * lin * vpr) return;
+  const int cv = (int)(i % vpr);
+  const long row = i / vpr;
+  const int b = (int)(row / lin), sr = (int)(row - (long)b * lin);
+  T* dst = dx + (size_t)row * dx_ld + dx_off + cv * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (accumulate) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dst), acc);
+  const int reach = (int)ceilf(1.0f / scale) + 2;  // the preimage of a source row is a run of at most ceil(1 / scale) virtual rows
+  int u0 = (int)floorf((float)sr / scale) - 1;
+  if (u0 < 0) u0 = 0;
+  const int u1 = sr == lin - 1 ? lvirt : min(lvirt, u0 + reach + 1);  // (the clamp sends every late row to the last source row)
+  for (int u = u0; u < u1; ++u) {
+    if (min((int)floorf((float)u * scale), lin - 1) != sr) continue;
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(du + ((size_t)b * lvirt + u) * du_ld + du_off + cv * VEC), v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+  }
+  *reinterpret_cast<u32x4*>(dst) = Elem<T>::pack(acc);
+}
+
 }  // namespace
 
 extern "C" int64_t tdx_train_workspace_floats(void) { return (int64_t)kRedBlocks * 4096; }
@@ -407,5 +464,44 @@ extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy
     hipLaunchKernelGGL(groupnorm_act_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, x_ld, (const __bf16*)dy, dy_ld, dy_off,
                        (__bf16*)dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate);
   TDX_CHECK_LAUNCH("groupnorm_act_bwd_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_interleave2(const void* even, const void* odd, void* out, int32_t out_ld, int32_t out_off, int32_t B, int32_t L, int32_t C,
+                               int32_t accumulate, int32_t dtype, void* stream) {
+  TDX_CHECK_ARG(even && out && (odd || L < 2), "tdx_interleave2: null pointer");
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_interleave2: bad dtype %d", dtype);
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  TDX_CHECK_ARG(B > 0 && L > 0 && C > 0 && C % vec == 0 && out_ld % vec == 0 && out_off % vec == 0 && out_off + C <= out_ld,
+                "tdx_interleave2: bad shape B=%d L=%d C=%d ld=%d off=%d", B, L, C, out_ld, out_off);
+  const long n = (long)B * L * (C / vec);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  const int le = (L + 1) / 2;
+  if (dtype == TDX_F32)
+    hipLaunchKernelGGL(interleave2_kernel<float>, grid, dim3(256), 0, st, (const float*)even, le, (const float*)odd, (float*)out, out_ld, out_off, B, L, C, accumulate);
+  else
+    hipLaunchKernelGGL(interleave2_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)even, le, (const __bf16*)odd, (__bf16*)out, out_ld, out_off, B, L, C, accumulate);
+  TDX_CHECK_LAUNCH("interleave2_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_upsample_fold(const void* du, int32_t du_ld, int32_t du_off, void* dx, int32_t dx_ld, int32_t dx_off, int32_t B, int32_t lin,
+                                 int32_t lvirt, int32_t C, int32_t accumulate, int32_t dtype, void* stream) {
+  TDX_CHECK_ARG(du && dx, "tdx_upsample_fold: null pointer");
+  TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_upsample_fold: bad dtype %d", dtype);
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  TDX_CHECK_ARG(B > 0 && lin > 0 && lvirt >= lin && C > 0 && C % vec == 0, "tdx_upsample_fold: bad shape B=%d lin=%d lvirt=%d C=%d", B, lin, lvirt, C);
+  TDX_CHECK_ARG(du_ld % vec == 0 && du_off % vec == 0 && du_off + C <= du_ld && dx_ld % vec == 0 && dx_off % vec == 0 && dx_off + C <= dx_ld,
+                "tdx_upsample_fold: leading dimensions / offsets must be multiples of %d and fit", vec);
+  const long n = (long)B * lin * (C / vec);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = (float)lin / (float)lvirt;
+  if (dtype == TDX_F32)
+    hipLaunchKernelGGL(upsample_fold_kernel<float>, grid, dim3(256), 0, st, (const float*)du, du_ld, du_off, (float*)dx, dx_ld, dx_off, B, lin, lvirt, C, scale, accumulate);
+  else
+    hipLaunchKernelGGL(upsample_fold_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)du, du_ld, du_off, (__bf16*)dx, dx_ld, dx_off, B, lin, lvirt, C, scale, accumulate);
+  TDX_CHECK_LAUNCH("upsample_fold_kernel");
   return TDX_OK;
 }

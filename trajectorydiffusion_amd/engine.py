@@ -57,6 +57,31 @@ def pack_conv_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return pack_conv_weight(w.detach().flip(2).transpose(0, 1).contiguous(), dtype)
 
 
+def pack_conv_weight_dgrad_stride2(w: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Weights of the two phases of a stride-2, k=3, pad-1 Conv1d's data gradient (see tdx_interleave2).
+
+    y[l] = sum_t W_t x[2l + t - 1]  =>  dx[2m] = W_1^T dy[m],  dx[2m + 1] = W_2^T dy[m] + W_0^T dy[m + 1]."""
+    w = w.detach()
+    wt = w.transpose(0, 1)                                   # (Cin, Cout, 3)
+    even = pack_conv_weight(wt[:, :, 1:2].contiguous(), dtype)
+    odd = torch.stack([torch.zeros_like(wt[:, :, 0]), wt[:, :, 2], wt[:, :, 0]], dim=2)   # taps read dy[m - 1], dy[m], dy[m + 1]
+    return even, pack_conv_weight(odd.contiguous(), dtype)
+
+
+def conv_dgrad_stride2(pg: "Program", dy: torch.Tensor, w_even: torch.Tensor, w_odd: torch.Tensor, dx: torch.Tensor, B: int, L: int,
+                       cout: int, cin: int, accumulate: bool = False) -> None:
+    """Record dx (B, L, cin) (+)= data gradient of a stride-2 conv from dy (B, ceil(L/2), cout): two tdx_conv_gemm launches on
+    dy (one per phase) and tdx_interleave2."""
+    lo = (L - 1) // 2 + 1
+    ev = torch.empty((B, lo, cin), device=dy.device, dtype=dy.dtype)
+    od = torch.empty((B, lo, cin), device=dy.device, dtype=dy.dtype)
+    pg.conv([Seg(dy, cout, cout, lo, taps=1)], w_even, None, ev, cin, B, lo, cin)
+    pg.conv([Seg(dy, cout, cout, lo, taps=3)], w_odd, None, od, cin, B, lo, cin)
+    pg.keep += [ev, od, dx]
+    pg.call("dgrad.interleave", pg.lib.tdx_interleave2, ev.data_ptr(), od.data_ptr(), dx.data_ptr(), dx.shape[-1], 0, B, L, cin,
+            1 if accumulate else 0, pg.code)
+
+
 class Seg:
     """One K-segment of a gathered GEMM (see tdx_kseg in include/trajdiff_hip.h)."""
     __slots__ = ("src", "ld", "ch_off", "cin", "taps", "stride", "lin", "lvirt")

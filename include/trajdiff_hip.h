@@ -208,6 +208,24 @@ int tdx_interleave2(const void* even, const void* odd, void* out, int32_t out_ld
 int tdx_upsample_fold(const void* du, int32_t du_ld, int32_t du_off, void* dx, int32_t dx_ld, int32_t dx_off, int32_t B, int32_t lin,
                       int32_t lvirt, int32_t C, int32_t accumulate, int32_t dtype, void* stream);
 
+/* y = act(z) and dz (+)= dy * act'(ref) on fp32 rows (n x c, row strides *_ld): ref = the pre-activation z for TDX_ACT_SWISH (Swish,
+ * ModelUtils.py:14), the pre-activation or the OUTPUT for TDX_ACT_LEAKY (LeakyReLU(0.1) keeps the sign). */
+int tdx_act_fwd(const float* z, int32_t z_ld, float* y, int32_t y_ld, int32_t n, int32_t c, int32_t act, void* stream);
+int tdx_act_bwd(const float* dy, int32_t dy_ld, const float* ref, int32_t ref_ld, float* dz, int32_t dz_ld, int32_t n, int32_t c, int32_t act,
+                int32_t accumulate, void* stream);
+
+/* out[b][c] (+)= sum over the L rows of trajectory b of x: gradient of the embed projection that conv1's epilogue broadcast over
+ * its rows (x + embed_proj(embed), TrajUNetBlocks.py:96). */
+int tdx_traj_rowsum(const float* x, int32_t ld, float* out, int32_t out_ld, int32_t B, int32_t L, int32_t c, int32_t accumulate, void* stream);
+
+/* nn.Embedding backward (TrajUNetBlocks.py:26-27,53-54): dtable[r][:] (+)= sum of dvec[b][j*dim : (j+1)*dim] over (b, j) with
+ * idx[b][j] == r; fixed summation order. */
+int tdx_embedding_bwd(const int64_t* idx, int32_t idx_ld, int32_t ncols, const float* dvec, int32_t dvec_ld, float* dtable, int32_t rows,
+                      int32_t dim, int32_t B, int32_t accumulate, void* stream);
+
+/* Backward of tdx_attention (fp32, L <= 16): dqkv (B, L, 3C) from qkv and the gradient dout (B, L, C) of its output. */
+int tdx_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t B, int32_t L, int32_t C, void* stream);
+
 /* torch.optim.AdamW single-tensor update (train.ipynb:131: lr 5e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01);
  * step counts from 1.  Hyper-parameters are doubles, as torch keeps them: 1 - beta2 must be formed before rounding to fp32. */
 int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,

@@ -224,3 +224,50 @@ def test_upsample_fold_is_the_gradient_of_nearest_interpolate(dt, li, lo):
         torch.cuda.synchronize()
         assert rel(dx.float().cpu()[:, :, 8:].permute(0, 2, 1), (acc + 1) * x.grad) < (1e-6 if dt == torch.float32 else 2e-2)
     assert float(dx[:, :, :8].abs().max()) == 0.0
+
+
+def test_small_backward_pieces():
+    """Activation fwd/bwd, per-trajectory row sums, nn.Embedding backward, attention backward against autograd (fp32)."""
+    _, _lib = _eng()
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    g = torch.Generator().manual_seed(3)
+    # swish / leaky
+    z = torch.randn(37, 256, generator=g, requires_grad=True)
+    dy = torch.randn(37, 256, generator=g)
+    for act, fn in ((2, lambda v: v * torch.sigmoid(v)), (1, lambda v: F.leaky_relu(v, 0.1))):
+        z.grad = None
+        y = fn(z)
+        y.backward(dy)
+        zd, dyd = z.detach().cuda(), dy.cuda()
+        yd, dz = torch.empty_like(zd), torch.ones_like(zd)
+        _lib.check(lib.tdx_act_fwd(zd.data_ptr(), 256, yd.data_ptr(), 256, 37, 256, act, st))
+        assert rel(yd.cpu(), y.detach()) < 2e-6
+        ref = zd if act == 2 else yd          # leaky: from the output
+        _lib.check(lib.tdx_act_bwd(dyd.data_ptr(), 256, ref.data_ptr(), 256, dz.data_ptr(), 256, 37, 256, act, 1, st))
+        assert rel(dz.cpu() - 1, z.grad) < 5e-6
+    # per-trajectory row sums
+    x = torch.randn(5, 13, 40, generator=g)
+    out = torch.zeros(5, 48, device="cuda")
+    xd = x.cuda()  # (device tensors stay referenced while the asynchronous launches read them)
+    _lib.check(lib.tdx_traj_rowsum(xd.data_ptr(), 40, out.data_ptr() + 8 * 4, 48, 5, 13, 40, 0, st))
+    assert rel(out.cpu()[:, 8:], x.sum(1)) < 1e-6 and float(out[:, :8].abs().max()) == 0.0
+    # embedding backward
+    table = torch.randn(33, 16, generator=g, requires_grad=True)
+    idx = torch.randint(0, 33, (50, 4), generator=g)
+    dvec = torch.randn(50, 4 * 16 + 8, generator=g)
+    F.embedding(idx, table).flatten(1).backward(dvec[:, :64])
+    dt_ = torch.empty(33, 16, device="cuda")
+    idxd, dvecd = idx.cuda(), dvec.cuda()
+    _lib.check(lib.tdx_embedding_bwd(idxd.data_ptr(), 4, 4, dvecd.data_ptr(), 72, dt_.data_ptr(), 33, 16, 50, 0, st))
+    assert rel(dt_.cpu(), table.grad) < 1e-6
+    # attention backward
+    for B, L, C in ((3, 13, 1024), (2, 7, 64), (1, 16, 128)):
+        qkv = torch.randn(B, L, 3 * C, generator=g, requires_grad=True)
+        qv, kv, vv = torch.split(qkv, C, dim=2)
+        o = torch.bmm(torch.softmax(torch.bmm(qv, kv.transpose(1, 2)) / C ** 0.5, dim=2), vv)
+        do = torch.randn(o.shape, generator=g)
+        o.backward(do)
+        dq = torch.empty(B, L, 3 * C, device="cuda")
+        qkvd, dod = qkv.detach().cuda(), do.cuda()
+        _lib.check(lib.tdx_attention_bwd(qkvd.data_ptr(), dod.data_ptr(), dq.data_ptr(), B, L, C, st))
+        assert rel(dq.cpu(), qkv.grad) < 2e-5, (B, L, C)

@@ -59,6 +59,11 @@ _SIGNATURES = {
                                      _i32, _i32, _vp]),
     "tdx_interleave2": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_upsample_fold": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_act_fwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_traj_rowsum": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_embedding_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_attention_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "tdx_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

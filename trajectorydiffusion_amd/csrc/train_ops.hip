@@ -359,6 +359,109 @@ __global__ __launch_bounds__(256) void upsample_fold_kernel(const T* __restrict_
   *reinterpret_cast<u32x4*>(dst) = Elem<T>::pack(acc);
 }
 
+// ---- small pieces ---------------------------------------------------------------------------------------------------------
+// act_fwd: y = act(z);  act_bwd: dz (+)= dy * act'(.), from the pre-activation z (swish) or from the OUTPUT y (leaky keeps the
+// sign, so a conv that applied it in its epilogue needs nothing saved).  fp32, strided rows.
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, int z_ld, float* __restrict__ y, int y_ld, int n, int c, int act) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n * c) return;
+  const int r = (int)(i / c), k = (int)(i - (long)r * c);
+  y[(size_t)r * y_ld + k] = tdx_act(z[(size_t)r * z_ld + k], act);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ ref, int ref_ld,
+                                                     float* __restrict__ dz, int dz_ld, int n, int c, int act, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n * c) return;
+  const int r = (int)(i / c), k = (int)(i - (long)r * c);
+  const float g = dy[(size_t)r * dy_ld + k], v = ref[(size_t)r * ref_ld + k];
+  float d = g;
+  if (act == TDX_ACT_SWISH) {
+    const float sg = 1.0f / (1.0f + __expf(-v));
+    d = g * (sg * (1.0f + v * (1.0f - sg)));
+  } else if (act == TDX_ACT_LEAKY) {
+    d = v > 0.f ? g : 0.1f * g;
+  }
+  float* o = dz + (size_t)r * dz_ld + k;
+  *o = accumulate ? *o + d : d;
+}
+
+// out[b][c] (+)= sum over the L rows of trajectory b of x[(b * L + l) * ld + c]: gradient of the per-trajectory embed bias
+// that a conv epilogue broadcast over its rows (TrajUNetBlocks.py:96).  One thread per (b, c), fixed order.
+__global__ __launch_bounds__(256) void traj_rowsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int out_ld, int B, int L,
+                                                         int c, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * c) return;
+  const int b = (int)(i / c), k = (int)(i - (long)b * c);
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) acc += x[((size_t)b * L + l) * ld + k];
+  float* o = out + (size_t)b * out_ld + k;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// nn.Embedding backward: dtable[r][c] (+)= sum over samples b and index columns j with idx[b * idx_ld + j] == r of
+// dvec[b * dvec_ld + j * dim + c].  One thread per table element scanning the batch: fixed order, no atomics.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ idx, int idx_ld, int ncols, const float* __restrict__ dvec,
+                                                           int dvec_ld, float* __restrict__ dtable, int rows, int dim, int B, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * dim) return;
+  const int r = (int)(i / dim), c = (int)(i - (long)r * dim);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < ncols; ++j)
+      if (idx[(size_t)b * idx_ld + j] == r) acc += dvec[(size_t)b * dvec_ld + j * dim + c];
+  dtable[i] = accumulate ? dtable[i] + acc : acc;
+}
+
+// Mid-block attention backward (TrajUNetBlocks.py:117-125), fp32, L <= 16 tokens: one workgroup per trajectory.
+//   S = Q K^T * scale, P = softmax(S), O = P V;  dV = P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dP * P)),
+//   dQ = dS K * scale, dK = dS^T Q * scale.   qkv / dqkv rows are (q | k | v) of 3 * C channels.
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                           int L, int C, float scale) {
+  __shared__ float P[16 * 16], dS[16 * 16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* base = qkv + (size_t)b * L * 3 * C;
+  const float* dob = dout + (size_t)b * L * C;
+  float* dbase = dqkv + (size_t)b * L * 3 * C;
+  const int i = tid >> 4, j = tid & 15;  // thread (i, j) owns score S[i][j] and dP[i][j]
+  float s = 0.f, dp = 0.f;
+  if (i < L && j < L) {
+    const float* q = base + (size_t)i * 3 * C;
+    const float* k = base + (size_t)j * 3 * C + C;
+    const float* v = base + (size_t)j * 3 * C + 2 * C;
+    const float* go = dob + (size_t)i * C;
+    for (int c = 0; c < C; ++c) {
+      s = fmaf(q[c], k[c], s);
+      dp = fmaf(go[c], v[c], dp);
+    }
+    s *= scale;
+  }
+  // softmax over j (16 consecutive lanes), masked to j < L
+  float m = (i < L && j < L) ? s : -INFINITY;
+  for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float e = (i < L && j < L) ? expf(s - m) : 0.f;
+  float sum = e;
+  for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float p = (i < L && j < L) ? e / sum : 0.f;
+  float t = dp * p;
+  for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+  P[tid] = p;
+  dS[tid] = p * (dp - t) * scale;   // already multiplied by the score scale
+  __syncthreads();
+  // dV[j][c] = sum_i P[i][j] dO[i][c];  dQ[i][c] = sum_j dS[i][j] K[j][c];  dK[j][c] = sum_i dS[i][j] Q[i][c]
+  for (int idx = tid; idx < L * C; idx += 256) {
+    const int r = idx / C, c = idx - r * C;
+    float dv = 0.f, dq = 0.f, dk = 0.f;
+    for (int o = 0; o < L; ++o) {
+      dv = fmaf(P[o * 16 + r], dob[(size_t)o * C + c], dv);
+      dq = fmaf(dS[r * 16 + o], base[(size_t)o * 3 * C + C + c], dq);
+      dk = fmaf(dS[o * 16 + r], base[(size_t)o * 3 * C + c], dk);
+    }
+    dbase[(size_t)r * 3 * C + c] = dq;
+    dbase[(size_t)r * 3 * C + C + c] = dk;
+    dbase[(size_t)r * 3 * C + 2 * C + c] = dv;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t tdx_train_workspace_floats(void) { return (int64_t)kRedBlocks * 4096; }
@@ -503,5 +606,50 @@ extern "C" int tdx_upsample_fold(const void* du, int32_t du_ld, int32_t du_off, 
   else
     hipLaunchKernelGGL(upsample_fold_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)du, du_ld, du_off, (__bf16*)dx, dx_ld, dx_off, B, lin, lvirt, C, scale, accumulate);
   TDX_CHECK_LAUNCH("upsample_fold_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_act_fwd(const float* z, int32_t z_ld, float* y, int32_t y_ld, int32_t n, int32_t c, int32_t act, void* stream) {
+  TDX_CHECK_ARG(z && y && n > 0 && c > 0 && z_ld >= c && y_ld >= c, "tdx_act_fwd: bad arguments");
+  TDX_CHECK_ARG(act >= TDX_ACT_NONE && act <= TDX_ACT_SWISH, "tdx_act_fwd: bad act %d", act);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)(((long)n * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, z_ld, y, y_ld, n, c, act);
+  TDX_CHECK_LAUNCH("act_fwd_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_act_bwd(const float* dy, int32_t dy_ld, const float* ref, int32_t ref_ld, float* dz, int32_t dz_ld, int32_t n, int32_t c,
+                           int32_t act, int32_t accumulate, void* stream) {
+  TDX_CHECK_ARG(dy && ref && dz && n > 0 && c > 0 && dy_ld >= c && ref_ld >= c && dz_ld >= c, "tdx_act_bwd: bad arguments");
+  TDX_CHECK_ARG(act >= TDX_ACT_NONE && act <= TDX_ACT_SWISH, "tdx_act_bwd: bad act %d", act);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(((long)n * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, ref, ref_ld, dz,
+                     dz_ld, n, c, act, accumulate);
+  TDX_CHECK_LAUNCH("act_bwd_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_traj_rowsum(const float* x, int32_t ld, float* out, int32_t out_ld, int32_t B, int32_t L, int32_t c, int32_t accumulate,
+                               void* stream) {
+  TDX_CHECK_ARG(x && out && B > 0 && L > 0 && c > 0 && ld >= c && out_ld >= c, "tdx_traj_rowsum: bad arguments");
+  hipLaunchKernelGGL(traj_rowsum_kernel, dim3((unsigned)(((long)B * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, out, out_ld, B, L, c,
+                     accumulate);
+  TDX_CHECK_LAUNCH("traj_rowsum_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_embedding_bwd(const int64_t* idx, int32_t idx_ld, int32_t ncols, const float* dvec, int32_t dvec_ld, float* dtable, int32_t rows,
+                                 int32_t dim, int32_t B, int32_t accumulate, void* stream) {
+  TDX_CHECK_ARG(idx && dvec && dtable && ncols > 0 && rows > 0 && dim > 0 && B > 0 && idx_ld >= ncols && dvec_ld >= ncols * dim,
+                "tdx_embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(((long)rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, idx_ld, ncols,
+                     dvec, dvec_ld, dtable, rows, dim, B, accumulate);
+  TDX_CHECK_LAUNCH("embedding_bwd_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t B, int32_t L, int32_t C, void* stream) {
+  TDX_CHECK_ARG(qkv && dout && dqkv && B > 0 && L > 0 && C > 0, "tdx_attention_bwd: bad arguments");
+  if (L > 16) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_attention_bwd: %d tokens > 16 supported", L);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, qkv, dout, dqkv, L, C, 1.0f / sqrtf((float)C));
+  TDX_CHECK_LAUNCH("attention_bwd_kernel");
   return TDX_OK;
 }

@@ -1,0 +1,376 @@
+"""One eps-MSE training step of TrajUNet on the HIP kernels (reference train.ipynb:198-209):
+
+    x_t = q_sample(x0, t, eps);  loss = mean((model(x_t, t, cat, num) - eps)^2);  loss.backward();  AdamW.step()
+
+fp32 throughout.  The forward pass is recorded op by op on a tape (every op = C-ABI launches in a forward `engine.Program`
+plus a closure that appends its gradient launches to a backward Program), so the backward pass is the tape in reverse: conv
+data gradients run on the forward conv kernel (tdx_conv_gemm on dy with repacked weights), weight gradients on
+tdx_conv_wgrad, GroupNorm+Swish on tdx_groupnorm_act_bwd, and so on (include/trajdiff_hip.h, "Training-step building
+blocks").  Activations are saved (no workspace reuse), statistics are recomputed.
+
+torch does plumbing only: device memory, the per-step re-packing of the weights (permute / cat / copy_ into fixed buffers),
+embedding-row gathers, layout changes of the (B, 2, L) model input/output, and zeroing of gradient buffers.
+
+Not covered yet: dropout (TrajUNetBlocks.py:85; the step runs with it off, like the parity fixture), bf16, DDP all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, engine
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_SWISH, KSeg, TdxError
+
+F32 = _lib.TDX_F32
+
+
+class _Src:
+    """One conv source: rows tensor (B, lin, ld), channel slice, taps / stride / nearest-upsample, and the slice of the weight
+    parameter (Cout, cin_total, k) that multiplies it."""
+
+    def __init__(self, t: torch.Tensor, cin: int, lin: int, W: torch.Tensor, taps: int = 3, stride: int = 1, ch_off: int = 0,
+                 lvirt: Optional[int] = None, w_off: int = 0, needs_grad: bool = True):
+        self.t, self.ld, self.cin, self.lin, self.W = t, t.shape[-1], cin, lin, W
+        self.taps, self.stride, self.ch_off, self.lvirt, self.w_off, self.needs_grad = taps, stride, ch_off, lin if lvirt is None else lvirt, w_off, needs_grad
+
+    def wslice(self) -> torch.Tensor:
+        return self.W.detach()[:, self.w_off:self.w_off + self.cin, :]
+
+
+class TrainStep:
+    def __init__(self, model, B: int, L: int, device: torch.device, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 0.01):
+        self.m, self.B, self.L, self.dev = model, B, L, device
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.lib = _lib.lib()
+        self.fw = engine.Program(device, torch.float32)
+        self.fw.release = lambda t: None            # saved activations: nothing is reused
+        self.bw = engine.Program(device, torch.float32)
+        self.bw.release = lambda t: None
+        self._back: List[Callable[[], None]] = []
+        self._repack: List[Callable[[], None]] = []
+        self._agrad: Dict[int, torch.Tensor] = {}   # id(activation) -> gradient buffer (zeroed every step)
+        self._keep: List[torch.Tensor] = []
+        self.params = dict(model.named_parameters())
+        for n, p in self.params.items():
+            if p.dtype != torch.float32 or p.device.type != "cuda" or not p.is_contiguous():
+                raise TdxError(f"TrainStep: parameter {n} must be a contiguous fp32 tensor on the GPU")
+        self.grads: Dict[str, torch.Tensor] = {}    # parameter name -> gradient (only parameters the forward pass uses)
+        self._pname = {id(p): n for n, p in self.params.items()}
+        self._padded: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Tuple[slice, ...]]] = []
+        self.ws = torch.empty(64 * 1024 * 1024 * 3 + 16, device=device, dtype=torch.float32)   # wgrad slabs (largest: 1024 x 1024 x 3)
+        self.red_ws = torch.empty(int(self.lib.tdx_train_workspace_floats()), device=device, dtype=torch.float32)
+        self.step_count = 0
+        self.state: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._build()
+
+    # ---- bookkeeping -----------------------------------------------------------------------------------------------------
+    def _new(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        t = torch.zeros(shape, device=self.dev, dtype=dtype)
+        self._keep.append(t)
+        return t
+
+    def G(self, t: torch.Tensor) -> torch.Tensor:
+        g = self._agrad.get(id(t))
+        if g is None:
+            g = self._agrad[id(t)] = self._new(*t.shape)
+        return g
+
+    def PG(self, p: torch.Tensor) -> torch.Tensor:
+        """Gradient buffer of a parameter (or of a padded stand-in registered with _pad)."""
+        n = self._pname.get(id(p))
+        if n is None:
+            raise TdxError("TrainStep: unknown parameter")
+        g = self.grads.get(n)
+        if g is None:
+            g = self.grads[n] = self._new(*p.shape)
+        return g
+
+    def _pad(self, p: torch.Tensor, shape: Sequence[int], where: Tuple[slice, ...]) -> torch.Tensor:
+        """A zero-padded copy of parameter p (channel counts the GEMM kernels can take), refreshed every step; its gradient is
+        folded back into p's gradient after the backward pass."""
+        q = self._new(*shape)
+        self._pname[id(q)] = "__pad%d" % len(self._padded)
+        self._repack.append(lambda: q[where].copy_(p.detach()))
+        self._padded.append((q, p, None, where))
+        return q
+
+    # ---- ops --------------------------------------------------------------------------------------------------------------
+    def conv(self, name: str, srcs: Sequence[_Src], cout: int, lout: int, out: torch.Tensor, out_off: int = 0,
+             biases: Sequence[torch.Tensor] = (), res: Optional[torch.Tensor] = None, ebias: Optional[Tuple[torch.Tensor, int]] = None,
+             act: int = ACT_NONE) -> None:
+        B, fw, lib = self.B, self.fw, self.lib
+        ktot = sum(s.taps * s.cin for s in srcs)
+        wp = self._new(cout, ktot)
+        self._repack.append(lambda: wp.copy_(torch.cat([engine.pack_conv_weight(s.wslice(), torch.float32) for s in srcs], dim=1)))
+        bsum = None
+        if biases:
+            bsum = self._new(cout)
+            self._repack.append(lambda: bsum.copy_(sum(b.detach() for b in biases)))
+        fw.conv([engine.Seg(s.t, s.ld, s.cin, s.lin, taps=s.taps, stride=s.stride, ch_off=s.ch_off, lvirt=s.lvirt) for s in srcs], wp, bsum,
+                out, out.shape[-1], B, lout, cout, out_off=out_off, act=act, res=res, res_ld=0 if res is None else res.shape[-1],
+                ebias=None if ebias is None else ebias[0], ebias_ld=0 if ebias is None else ebias[0].shape[-1],
+                ebias_off=0 if ebias is None else ebias[1], name=name)
+        dgrad_w = []
+        for s in srcs:
+            if not s.needs_grad:
+                dgrad_w.append(None)
+            elif s.stride == 2:
+                we, wo = self._new(s.cin, cout), self._new(s.cin, 3 * cout)
+
+                def rp(s=s, we=we, wo=wo):
+                    a, b = engine.pack_conv_weight_dgrad_stride2(s.wslice(), torch.float32)
+                    we.copy_(a)
+                    wo.copy_(b)
+                self._repack.append(rp)
+                dgrad_w.append((we, wo))
+            else:
+                wd = self._new(s.cin, s.taps * cout)
+                self._repack.append(lambda s=s, wd=wd: wd.copy_(engine.pack_conv_weight_dgrad(s.wslice(), torch.float32)))
+                dgrad_w.append(wd)
+
+        def backward():
+            bw, N = self.bw, B * lout
+            go, ld, off = self.G(out), out.shape[-1], out_off
+            if act == ACT_LEAKY:   # (only the embedding MLP: lout == 1)
+                dz = self._new(B, lout, cout)
+                bw.call(name + ".act_bwd", lib.tdx_act_bwd, go.data_ptr() + 4 * off, ld, out.data_ptr() + 4 * off, ld, dz.data_ptr(), cout, N, cout,
+                        ACT_LEAKY, 0)
+                go, ld, off = dz, cout, 0
+            elif act != ACT_NONE:
+                raise TdxError(f"{name}: activation {act} in a conv epilogue has no backward here")
+            gptr = go.data_ptr() + 4 * off
+            if res is not None:
+                gr = self.G(res)
+                bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout, 1, F32)
+            for b in biases:
+                bw.call(name + ".dbias", lib.tdx_colsum, gptr, ld, N, cout, self.PG(b).data_ptr(), 1, F32, self.red_ws.data_ptr())
+            if ebias is not None:
+                ge = self.G(ebias[0])
+                bw.call(name + ".debias", lib.tdx_traj_rowsum, gptr, ld, ge.data_ptr() + 4 * ebias[1], ge.shape[-1], B, lout, cout, 1)
+            for s, wd in zip(srcs, dgrad_w):
+                k = KSeg(s.t.data_ptr(), float(torch.tensor(float(s.lin), dtype=torch.float32) / torch.tensor(float(s.lvirt), dtype=torch.float32)),
+                         0, s.ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt, 0)
+                self._keep.append(k)
+                gw = self.PG(s.W)
+                bw.call(name + ".wgrad", lib.tdx_conv_wgrad, go.data_ptr(), ld, off, cout, C.byref(k), B, lout, gw.data_ptr(), s.W.shape[1], s.w_off, 1,
+                        F32, self.ws.data_ptr(), self.ws.numel())
+                if wd is None:
+                    continue
+                gs = self.G(s.t)
+                if s.stride == 2:
+                    if off != 0 or ld != cout or s.ch_off != 0 or s.ld != s.cin:
+                        raise TdxError(f"{name}: stride-2 data gradient needs plain tensors")
+                    engine.conv_dgrad_stride2(bw, go, wd[0], wd[1], gs, B, s.lin, cout, s.cin, accumulate=True)
+                elif s.lvirt != s.lin:
+                    du = self._new(B, s.lvirt, s.cin)
+                    bw.conv([engine.Seg(go, ld, cout, lout, taps=s.taps, ch_off=off)], wd, None, du, s.cin, B, s.lvirt, s.cin, name=name + ".dgrad")
+                    bw.call(name + ".fold", lib.tdx_upsample_fold, du.data_ptr(), s.cin, 0, gs.data_ptr(), s.ld, s.ch_off, B, s.lin, s.lvirt, s.cin, 1, F32)
+                else:
+                    bw.conv([engine.Seg(go, ld, cout, lout, taps=s.taps, ch_off=off)], wd, None, gs, s.ld, B, s.lin, s.cin, out_off=s.ch_off,
+                            res=gs[..., s.ch_off:], res_ld=s.ld, name=name + ".dgrad")
+        self._back.append(backward)
+
+    def gn(self, name: str, x: torch.Tensor, Cn: int, L: int, out: torch.Tensor, out_off: int, mod, p_off: int, groups: int, act: int) -> None:
+        B, lib = self.B, self.lib
+        gam, bet = mod.weight, mod.bias
+        self.fw.groupnorm(x, x.shape[-1], out, out.shape[-1], out_off, gam.data, bet.data, p_off, B, L, Cn, groups, mod.eps, act, name=name)
+
+        def backward():
+            ra, rb = self._new(B, Cn), self._new(B, Cn)
+            go, gx = self.G(out), self.G(x)
+            self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_bwd, x.data_ptr(), x.shape[-1], go.data_ptr(), out.shape[-1], out_off, gx.data_ptr(),
+                         x.shape[-1], 0, gam.data.data_ptr() + 4 * p_off, bet.data.data_ptr() + 4 * p_off, ra.data_ptr(), rb.data_ptr(), B, L, Cn, groups,
+                         mod.eps, act, 1, F32)
+            for rows, p in ((ra, gam), (rb, bet)):
+                self.bw.call(name + ".dparam", lib.tdx_colsum, rows.data_ptr(), Cn, B, Cn, self.PG(p).data_ptr() + 4 * p_off, 1, F32, self.red_ws.data_ptr())
+        self._back.append(backward)
+
+    # ---- the network ------------------------------------------------------------------------------------------------------
+    def _resblock(self, key: str, blk, srcs: List[Tuple[torch.Tensor, int]], L: int) -> torch.Tensor:
+        """ResnetBlock (TrajUNetBlocks.py:92-99); srcs = the (possibly concatenated) raw input as [(rows tensor, channels)]."""
+        B = self.B
+        cin, cout = blk.in_c, blk.out_c
+        a1 = self._new(B, L, cin)
+        off = 0
+        for t, c in srcs:   # GroupNorm(32, cin) over a concat of equal halves = GroupNorm(16) over each half
+            self.gn(key + "gn1", t, c, L, a1, off, blk.stage1[0], off, blk.norm_groups * c // cin, ACT_SWISH)
+            off += c
+        h = self._new(B, L, cout)
+        self.conv(key + "conv1", [_Src(a1, cin, L, blk.stage1[2].weight)], cout, L, h, biases=[blk.stage1[2].bias],
+                  ebias=(self.E, self.m.embed_offsets[key]))
+        a2 = self._new(B, L, cout)
+        self.gn(key + "gn2", h, cout, L, a2, 0, blk.stage2[0], 0, blk.norm_groups, ACT_SWISH)
+        y = self._new(B, L, cout)
+        s2 = [_Src(a2, cout, L, blk.stage2[3].weight)]
+        if blk.has_shortcut:
+            off = 0
+            for t, c in srcs:
+                s2.append(_Src(t, c, L, blk.shortcut.weight, taps=1, w_off=off))
+                off += c
+            self.conv(key + "conv2", s2, cout, L, y, biases=[blk.stage2[3].bias, blk.shortcut.bias])
+        else:
+            self.conv(key + "conv2", s2, cout, L, y, biases=[blk.stage2[3].bias], res=srcs[0][0])
+        return y
+
+    def _build(self) -> None:
+        m, B, L, lib = self.m, self.B, self.L, self.lib
+        cs, R, S = m.channel_schedule, m.res_blocks, m.stages
+        emb = m.embed_block
+        # ---- embedding (TrajUNetBlocks.py:45-62) ----
+        self.pe, self.catvec, self.num4 = self._new(B, 1, 128), self._new(B, 1, 1280), self._new(B, 1, 4)
+        t0, t2 = emb.time_embed_layers[0], emb.time_embed_layers[2]
+        cf, d1, d3 = emb.categorical_fc, emb.deep_fc[1], emb.deep_fc[3]
+        h1 = self._new(B, 1, 128)
+        self._lin("embed.time0", self.pe, 128, t0, h1, 0, ACT_LEAKY, needs_grad=False)
+        z = self._new(B, 1, 256)
+        self._lin("embed.time2", h1, 128, t2, z, 0, ACT_NONE)
+        deep_in = self._new(B, 1, 1024)
+        self._lin("embed.cat_fc", self.catvec, 1280, cf, deep_in, 0, ACT_LEAKY)
+        wide4 = self._pad(emb.wide_fc.weight, (256, 4, 1), (slice(None), slice(0, 3), 0))
+        self._lin("embed.wide", self.num4, 4, emb.wide_fc, deep_in, 768, ACT_LEAKY, W=wide4, needs_grad=False)
+        hd = self._new(B, 1, 512)
+        self._lin("embed.deep1", deep_in, 1024, d1, hd, 0, ACT_LEAKY)
+        self._lin("embed.deep3", hd, 512, d3, z, 128, ACT_NONE)
+        e = self._new(B, 1, 256)
+        self.fw.call("embed.swish", lib.tdx_act_fwd, z.data_ptr(), 256, e.data_ptr(), 256, B, 256, ACT_SWISH)
+        self._back.append(lambda: self.bw.call("embed.swish.bwd", lib.tdx_act_bwd, self.G(e).data_ptr(), 256, z.data_ptr(), 256, self.G(z).data_ptr(), 256,
+                                               B, 256, ACT_SWISH, 1))
+
+        def emb_tables():
+            gc = self.G(self.catvec)
+            self.bw.call("embed.cell.bwd", lib.tdx_embedding_bwd, self.cat.data_ptr(), 5, 4, gc.data_ptr(), 1280,
+                         self.PG(emb.cell_index_embedder.weight).data_ptr(), 256, 256, B, 1)
+            self.bw.call("embed.day.bwd", lib.tdx_embedding_bwd, self.cat.data_ptr() + 8 * 4, 5, 1, gc.data_ptr() + 4 * 1024, 1280,
+                         self.PG(emb.day_embedder.weight).data_ptr(), 33, 256, B, 1)
+        self._back.insert(0, emb_tables)   # runs LAST in the backward pass (the list is replayed in reverse)
+        self.cat = self._new(B, 5, dtype=torch.int64)
+        # ---- per-block embed projections (TrajUNetBlocks.py:89,96): E[:, off : off + out_c] ----
+        self.E = self._new(B, 1, m.embed_cols)
+        for key, blk in m.executed_resblocks():
+            self._lin(key + "embed_proj", e, 256, blk.embed_proj, self.E, m.embed_offsets[key], ACT_NONE, W=blk.embed_proj.weight)
+        # ---- UNet (TrajUNet.py:98-112) ----
+        lens = [L]
+        for _ in range(S):
+            lens.append(engine.conv_out_len(lens[-1], 2))
+        self.x4 = self._new(B, L, 4)
+        stem4 = self._pad(m.stem.weight, (cs[0], 4, 3), (slice(None), slice(0, 2), slice(None)))
+        cur = self._new(B, L, cs[0])
+        self.conv("stem", [_Src(self.x4, 4, L, stem4, needs_grad=False)], cs[0], L, cur, biases=[m.stem.bias])
+        downs = []
+        for i in range(S):
+            for j in range(R):
+                blk = m.down_blocks[i][j]
+                cur = self._resblock(f"down_blocks.{i}.{j}.", blk, [(cur, blk.in_c)], lens[i])
+            dconv = m.down_blocks[i][R]
+            d = self._new(B, lens[i + 1], cs[i + 1])
+            self.conv(f"down_blocks.{i}.down", [_Src(cur, cs[i + 1], lens[i], dconv.weight, stride=2)], cs[i + 1], lens[i + 1], d, biases=[dconv.bias])
+            downs.append(d)
+            cur = d
+        ab, key, Cn, lm = m.mid_attn_block, "mid_attn_block.", cs[-1], lens[-1]
+        x1 = self._resblock(key + "res1.", ab.res1, [(cur, Cn)], lm)
+        a = self._new(B, lm, Cn)
+        self.gn(key + "qkv_gn", x1, Cn, lm, a, 0, ab.qkv_getter[0], 0, ab.norm_groups, ACT_NONE)
+        qkv = self._new(B, lm, 3 * Cn)
+        self.conv(key + "qkv", [_Src(a, Cn, lm, ab.qkv_getter[1].weight, taps=1)], 3 * Cn, lm, qkv, biases=[ab.qkv_getter[1].bias])
+        o = self._new(B, lm, Cn)
+        self.fw.call(key + "attention", lib.tdx_attention, qkv.data_ptr(), o.data_ptr(), B, lm, Cn, F32)
+        self._back.append(lambda: self.bw.call(key + "attention.bwd", lib.tdx_attention_bwd, qkv.data_ptr(), self.G(o).data_ptr(), self.G(qkv).data_ptr(),
+                                               B, lm, Cn))
+        x2 = self._new(B, lm, Cn)
+        self.conv(key + "proj", [_Src(o, Cn, lm, ab.project_out.weight, taps=1)], Cn, lm, x2, biases=[ab.project_out.bias], res=x1)
+        cur = self._resblock(key + "res2.", ab.res2, [(x2, Cn)], lm)
+        for i in range(S):
+            skip, li, lo = downs[-i - 1], lens[S - i], lens[S - i - 1]
+            cskip, co = cs[S - i], cs[S - i - 1]
+            srcs = [(cur, cskip), (skip, cskip)]
+            for j in range(R - 1):
+                cur = self._resblock(f"up_blocks.{i}.{j}.", m.up_blocks[i][j], srcs, li)
+                srcs = [(cur, co)]
+            uconv = m.up_blocks[i][R]
+            nxt = self._new(B, lo, co)
+            self.conv(f"up_blocks.{i}.up", [_Src(cur, co, li, uconv.weight, lvirt=lo)], co, lo, nxt, biases=[uconv.bias])
+            cur = nxt
+        gh, hc = m.head[0], m.head[1]
+        ah = self._new(B, L, cs[0])
+        self.gn("head.gn", cur, cs[0], L, ah, 0, gh, 0, gh.num_groups, ACT_NONE)
+        head4 = self._pad(hc.weight, (4, cs[0], 3), (slice(0, 2), slice(None), slice(None)))
+        hb4 = self._pad(hc.bias, (4,), (slice(0, 2),))
+        self.out4 = self._new(B, L, 4)
+        self.conv("head.conv", [_Src(ah, cs[0], L, head4)], 4, L, self.out4, biases=[hb4])
+        # ---- backward program = the tape in reverse ----
+        for f in reversed(self._back):
+            f()
+        self.pred = self._new(B, 2, L)
+        self.dpred = self._new(B, 2, L)
+        self.loss = self._new(1)
+
+    def _lin(self, name: str, src: torch.Tensor, k: int, mod, out: torch.Tensor, off: int, act: int, W: Optional[torch.Tensor] = None,
+             needs_grad: bool = True) -> None:
+        """nn.Linear / Conv1d(k=1) on (B, 1, k) rows."""
+        if W is None:   # nn.Linear weight (out, in) as a Conv1d(k=1) weight through a registered view
+            W = mod.weight.unsqueeze(2)
+            self._keep.append(W)
+            self._pname[id(W)] = self._pname[id(mod.weight)] + "::k1"
+            self._padded.append((W, mod.weight, None, None))
+        self.conv(name, [_Src(src, k, 1, W, taps=1, needs_grad=needs_grad)], W.shape[0], 1, out, out_off=off, biases=[mod.bias], act=act)
+
+    # ---- one step -----------------------------------------------------------------------------------------------------------
+    def forward_backward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """Loss (device scalar) and gradients (self.grads, by parameter name) of mean((model(x_t, t, cat, num) - eps)^2)."""
+        m, B, L = self.m, self.B, self.L
+        emb = m.embed_block
+        if tuple(x_t.shape) != (B, 2, L):
+            raise TdxError(f"TrainStep: expected x_t of shape {(B, 2, L)}, got {tuple(x_t.shape)}")
+        if int(t.min()) < 0 or int(t.max()) >= emb.pos_enc.shape[0] or int(cat[:, :4].min()) < 0 or int(cat[:, :4].max()) > 255 or \
+                int(cat[:, 4].min()) < 0 or int(cat[:, 4].max()) > 32:
+            raise IndexError("TrainStep: time step or categorical attribute out of range")
+        with torch.no_grad():
+            for f in self._repack:
+                f()
+            for g in self._agrad.values():
+                g.zero_()
+            for g in self.grads.values():
+                g.zero_()
+            # plumbing: layouts and embedding-row gathers
+            self.x4.zero_()
+            self.x4[:, :, :2].copy_(x_t.permute(0, 2, 1))
+            self.pe[:, 0, :].copy_(emb.pos_enc.to(self.dev)[t])
+            self.cat.copy_(cat)
+            self.catvec[:, 0, :1024].copy_(emb.cell_index_embedder.weight.detach()[cat[:, :4]].flatten(1))
+            self.catvec[:, 0, 1024:].copy_(emb.day_embedder.weight.detach()[cat[:, 4]])
+            self.num4.zero_()
+            self.num4[:, 0, :3].copy_(num)
+            self.fw.run()
+            self.pred.copy_(self.out4[:, :, :2].permute(0, 2, 1))
+            epsc = eps.contiguous()
+            _lib.check(self.lib.tdx_mse_loss_grad(self.pred.data_ptr(), epsc.data_ptr(), self.dpred.data_ptr(), self.loss.data_ptr(), self.pred.numel(),
+                                                  self.red_ws.data_ptr(), _lib.stream_ptr()), "tdx_mse_loss_grad")
+            self.G(self.out4)[:, :, :2].copy_(self.dpred.permute(0, 2, 1))
+            self.bw.run()
+            for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters
+                gq = self.grads.get(self._pname[id(q)])
+                if gq is None:
+                    continue
+                gp = self.grads.get(self._pname[id(p)])
+                if gp is None:
+                    gp = self.grads[self._pname[id(p)]] = self._new(*p.shape)
+                gp.add_(gq[where].reshape(p.shape) if where is not None else gq.reshape(p.shape))
+        return self.loss
+
+    def named_gradients(self) -> Dict[str, torch.Tensor]:
+        return {n: g for n, g in self.grads.items() if n in self.params}
+
+    def optimizer_step(self) -> None:
+        """torch.optim.AdamW(lr, betas, eps, weight_decay) over every parameter that received a gradient (train.ipynb:131,208)."""
+        self.step_count += 1
+        st = _lib.stream_ptr()
+        for n, g in self.named_gradients().items():
+            p = self.params[n]
+            if n not in self.state:
+                self.state[n] = (torch.zeros_like(p), torch.zeros_like(p))
+            mm, vv = self.state[n]
+            _lib.check(self.lib.tdx_adamw_step(p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.wd, self.step_count, st), "tdx_adamw_step")

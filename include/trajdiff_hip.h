@@ -226,6 +226,10 @@ int tdx_embedding_bwd(const int64_t* idx, int32_t idx_ld, int32_t ncols, const f
 /* Backward of tdx_attention (fp32, L <= 16): dqkv (B, L, 3C) from qkv and the gradient dout (B, L, C) of its output. */
 int tdx_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t B, int32_t L, int32_t C, void* stream);
 
+/* nn.Dropout(p), training mode (TrajUNetBlocks.py:85), in place on fp32 rows: x *= keep / (1 - p).  The mask comes from Philox4x32-10
+ * keyed by (seed, step_ctr[0], layer, element index): calling it again with the same key on the gradient is the backward pass. */
+int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, uint64_t seed, uint32_t layer, const int32_t* step_ctr, void* stream);
+
 /* torch.optim.AdamW single-tensor update (train.ipynb:131: lr 5e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01);
  * step counts from 1.  Hyper-parameters are doubles, as torch keeps them: 1 - beta2 must be formed before rounding to fp32. */
 int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,

@@ -102,9 +102,11 @@ def test_forward_rejects_what_it_cannot_run(model):
     bad_c = cat.clone(); bad_c[1, 0] = 256
     with pytest.raises(IndexError):
         model(x.cuda(), t.cuda(), bad_c.cuda(), num.cuda())
-    model.train()
+    model.train()   # training mode runs (tests/test_gpu_training.py), with the same no-fallback rule
+    with pytest.raises(TdxError):
+        model(x, t, cat, num)
     with pytest.raises(NotImplementedError):
-        model(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+        model.down_blocks[0][0](torch.zeros(2, 128, 200, device="cuda"), torch.zeros(2, 256, 1, device="cuda"))   # blocks on their own: inference only
     model.eval()
 
 

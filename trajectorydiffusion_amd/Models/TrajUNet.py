@@ -266,6 +266,11 @@ class TrajUNet(_HipBlock):
 
     # ---- the reference's forward ----------------------------------------------------------------
     def forward(self, x: torch.Tensor, time: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor) -> torch.Tensor:
+        if self.training:   # train.ipynb:204: fp32, dropout on, differentiable w.r.t. the parameters (training.py)
+            from ..training import train_forward
+            if x.dim() != 3 or x.shape[1] != 2:
+                raise TdxError(f"TrajUNet.forward: x must be (B, 2, L), got {tuple(x.shape)}")
+            return train_forward(self, x, time, cat_attr, num_attr)
         self._guard(x, time, cat_attr, num_attr)
         if x.dim() != 3 or x.shape[1] != 2:
             raise TdxError(f"TrajUNet.forward: x must be (B, 2, L), got {tuple(x.shape)}")

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "tdx_traj_rowsum": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_embedding_bwd": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tdx_attention_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "tdx_dropout": (_i32, [_vp, _i32, _i32, _i32, _f32, _u64, C.c_uint32, _vp, _vp]),
     "tdx_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -462,6 +462,25 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   }
 }
 
+// nn.Dropout(p) in training mode (TrajUNetBlocks.py:85): x *= keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10 keyed by
+// (seed, step, layer) and the element's logical index, so the backward pass regenerates the same mask from the same call.
+__global__ __launch_bounds__(256) void dropout_kernel(float* __restrict__ x, int ld, int n, int c, uint32_t thresh, float scale, uint64_t seed,
+                                                     uint32_t layer, const int32_t* __restrict__ step_ctr) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;   // one Philox call = 4 consecutive elements
+  const long total = (long)n * c;
+  if (q * 4 >= total) return;
+  uint32_t r[4];
+  philox4((uint64_t)q, layer, seed ^ ((uint64_t)(uint32_t)step_ctr[0] << 32), r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long e = q * 4 + j;
+    if (e >= total) break;
+    const int row = (int)(e / c), k = (int)(e - (long)row * c);
+    float* px = x + (size_t)row * ld + k;
+    *px = r[j] >= thresh ? *px * scale : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t tdx_train_workspace_floats(void) { return (int64_t)kRedBlocks * 4096; }
@@ -651,5 +670,17 @@ extern "C" int tdx_attention_bwd(const float* qkv, const float* dout, float* dqk
   if (L > 16) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_attention_bwd: %d tokens > 16 supported", L);
   hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, qkv, dout, dqkv, L, C, 1.0f / sqrtf((float)C));
   TDX_CHECK_LAUNCH("attention_bwd_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, uint64_t seed, uint32_t layer, const int32_t* step_ctr,
+                           void* stream) {
+  TDX_CHECK_ARG(x && step_ctr && n > 0 && c > 0 && ld >= c, "tdx_dropout: bad arguments");
+  TDX_CHECK_ARG(p >= 0.f && p < 1.f, "tdx_dropout: p=%f not in [0, 1)", (double)p);
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const long quads = ((long)n * c + 3) / 4;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, n, c, thresh,
+                     1.0f / (1.0f - p), seed, layer, step_ctr);
+  TDX_CHECK_LAUNCH("dropout_kernel");
   return TDX_OK;
 }

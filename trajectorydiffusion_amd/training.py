@@ -41,7 +41,7 @@ class _Src:
 
 class TrainStep:
     def __init__(self, model, B: int, L: int, device: torch.device, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.01):
+                 eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: int = 0):
         self.m, self.B, self.L, self.dev = model, B, L, device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lib = _lib.lib()
@@ -64,6 +64,11 @@ class TrainStep:
         self.red_ws = torch.empty(int(self.lib.tdx_train_workspace_floats()), device=device, dtype=torch.float32)
         self.step_count = 0
         self.state: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.dropout = dropout          # None: each ResnetBlock's own p (0.1, TrajUNetBlocks.py:66); 0.0 switches it off
+        self.seed = seed
+        self.rng = torch.zeros(4, dtype=torch.int32, device=device)   # [0] = forward-pass counter, read by tdx_dropout
+        self._passes = 0
+        self._layer = 0
         self._build()
 
     # ---- bookkeeping -----------------------------------------------------------------------------------------------------
@@ -203,6 +208,13 @@ class TrainStep:
                   ebias=(self.E, self.m.embed_offsets[key]))
         a2 = self._new(B, L, cout)
         self.gn(key + "gn2", h, cout, L, a2, 0, blk.stage2[0], 0, blk.norm_groups, ACT_SWISH)
+        p = blk.dropout if self.dropout is None else self.dropout
+        if p > 0.0:   # nn.Dropout in stage2 (TrajUNetBlocks.py:85); the same call on the gradient is its backward
+            self._layer += 1
+            layer = self._layer
+            self.fw.call(key + "dropout", self.lib.tdx_dropout, a2.data_ptr(), cout, B * L, cout, p, self.seed, layer, self.rng.data_ptr())
+            self._back.append(lambda: self.bw.call(key + "dropout.bwd", self.lib.tdx_dropout, self.G(a2).data_ptr(), cout, B * L, cout, p, self.seed,
+                                                   layer, self.rng.data_ptr()))
         y = self._new(B, L, cout)
         s2 = [_Src(a2, cout, L, blk.stage2[3].weight)]
         if blk.has_shortcut:
@@ -318,22 +330,22 @@ class TrainStep:
         self.conv(name, [_Src(src, k, 1, W, taps=1, needs_grad=needs_grad)], W.shape[0], 1, out, out_off=off, biases=[mod.bias], act=act)
 
     # ---- one step -----------------------------------------------------------------------------------------------------------
-    def forward_backward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
-        """Loss (device scalar) and gradients (self.grads, by parameter name) of mean((model(x_t, t, cat, num) - eps)^2)."""
+    def forward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor) -> torch.Tensor:
+        """eps_hat (B, 2, L) of the training-mode forward pass; activations stay saved for backward()."""
         m, B, L = self.m, self.B, self.L
         emb = m.embed_block
         if tuple(x_t.shape) != (B, 2, L):
             raise TdxError(f"TrainStep: expected x_t of shape {(B, 2, L)}, got {tuple(x_t.shape)}")
+        for v in (x_t, t, cat, num):
+            _lib.require_device(v, "TrainStep input")
         if int(t.min()) < 0 or int(t.max()) >= emb.pos_enc.shape[0] or int(cat[:, :4].min()) < 0 or int(cat[:, :4].max()) > 255 or \
                 int(cat[:, 4].min()) < 0 or int(cat[:, 4].max()) > 32:
             raise IndexError("TrainStep: time step or categorical attribute out of range")
         with torch.no_grad():
             for f in self._repack:
                 f()
-            for g in self._agrad.values():
-                g.zero_()
-            for g in self.grads.values():
-                g.zero_()
+            self._passes += 1
+            self.rng[0] = self._passes
             # plumbing: layouts and embedding-row gathers
             self.x4.zero_()
             self.x4[:, :, :2].copy_(x_t.permute(0, 2, 1))
@@ -345,10 +357,16 @@ class TrainStep:
             self.num4[:, 0, :3].copy_(num)
             self.fw.run()
             self.pred.copy_(self.out4[:, :, :2].permute(0, 2, 1))
-            epsc = eps.contiguous()
-            _lib.check(self.lib.tdx_mse_loss_grad(self.pred.data_ptr(), epsc.data_ptr(), self.dpred.data_ptr(), self.loss.data_ptr(), self.pred.numel(),
-                                                  self.red_ws.data_ptr(), _lib.stream_ptr()), "tdx_mse_loss_grad")
-            self.G(self.out4)[:, :, :2].copy_(self.dpred.permute(0, 2, 1))
+        return self.pred
+
+    def backward(self, dpred: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Gradients of every used parameter (by name) for the gradient dpred (B, 2, L) of the last forward()'s output."""
+        with torch.no_grad():
+            for g in self._agrad.values():
+                g.zero_()
+            for g in self.grads.values():
+                g.zero_()
+            self.G(self.out4)[:, :, :2].copy_(dpred.permute(0, 2, 1))
             self.bw.run()
             for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters
                 gq = self.grads.get(self._pname[id(q)])
@@ -358,6 +376,15 @@ class TrainStep:
                 if gp is None:
                     gp = self.grads[self._pname[id(p)]] = self._new(*p.shape)
                 gp.add_(gq[where].reshape(p.shape) if where is not None else gq.reshape(p.shape))
+        return self.named_gradients()
+
+    def forward_backward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """Loss (device scalar) and gradients (self.grads, by parameter name) of mean((model(x_t, t, cat, num) - eps)^2)."""
+        pred = self.forward(x_t, t, cat, num)
+        epsc = eps.contiguous()
+        _lib.check(self.lib.tdx_mse_loss_grad(pred.data_ptr(), epsc.data_ptr(), self.dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
+                                              self.red_ws.data_ptr(), _lib.stream_ptr()), "tdx_mse_loss_grad")
+        self.backward(self.dpred)
         return self.loss
 
     def named_gradients(self) -> Dict[str, torch.Tensor]:
@@ -374,3 +401,33 @@ class TrainStep:
             mm, vv = self.state[n]
             _lib.check(self.lib.tdx_adamw_step(p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), self.lr, self.betas[0],
                                                self.betas[1], self.eps, self.wd, self.step_count, st), "tdx_adamw_step")
+
+
+class _TrainForward(torch.autograd.Function):
+    """Makes the training-mode forward pass a node of torch's autograd graph, so the reference's loop (train.ipynb:198-209:
+    loss = MSELoss()(model(...), eps); loss.backward(); optimizer.step()) runs unchanged: backward() runs the HIP backward
+    program and hands every parameter its gradient."""
+
+    @staticmethod
+    def forward(ctx, ts: "TrainStep", x_t, t, cat, num, *params):
+        ctx.ts, ctx.names, ctx.version = ts, [ts._pname[id(p)] for p in params], ts._passes + 1
+        return ts.forward(x_t, t, cat, num).clone()
+
+    @staticmethod
+    def backward(ctx, dpred):
+        ts = ctx.ts
+        if ts._passes != ctx.version:
+            raise TdxError("TrajUNet (training mode): backward() must follow the forward() it belongs to (one graph at a time per batch shape)")
+        grads = ts.backward(dpred.contiguous())
+        return (None, None, None, None, None) + tuple(grads[n].clone() if n in grads else None for n in ctx.names)
+
+
+def train_forward(model, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor) -> torch.Tensor:
+    """model(x_t, t, cat, num) in training mode (dropout on), differentiable w.r.t. the parameters."""
+    B, _, L = x_t.shape
+    cache = model.__dict__.setdefault("_train_steps", {})
+    ts = cache.get((B, L))
+    if ts is None:
+        ts = cache[(B, L)] = TrainStep(model, B, L, x_t.device)
+    params = [p for p in model.parameters()]
+    return _TrainForward.apply(ts, x_t, t, cat, num, *params)

@@ -183,10 +183,13 @@ int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int3
 /* Weight gradient of one K-segment of tdx_conv_gemm (autograd of nn.Conv1d, TrajUNetBlocks.py:77,86,89):
  *   dw[co][ci_off + ci][t] (+)= sum over output rows n of dy[n * dy_ld + dy_off + co] * X[src(n, t)][ci],
  * dw in the reference layout (Cout, cin_total, taps) fp32, src(n, t) = the forward row map of `seg` (padding, stride 2,
- * nearest-upsampled source).  ws holds splits * cout * cin * taps floats (splits <= 64, chosen to fit ws_floats). */
+ * nearest-upsampled source).  ws holds splits * cout * cin * taps floats (splits <= 512, chosen to fit ws_floats); the
+ * partial sums are added in split order, so the result does not depend on scheduling. */
 int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
                    float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
                    void* stream);
+/* Test hook, no reference counterpart: bit 0 keeps tdx_conv_wgrad off its large-tile kernel.  Returns the previous value. */
+int tdx_conv_wgrad_debug(int32_t force);
 
 /* Backward of tdx_groupnorm_act (nn.GroupNorm + Swish, TrajUNetBlocks.py:75-76,83-84): from the forward INPUT x and the
  * gradient dy of the activated output, dx (+)= gradient of x; dgamma_rows / dbeta_rows (B, C) fp32 receive each

@@ -85,7 +85,8 @@ def test_colsum(dt, n, c):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("case", ["k3", "k3_s2", "k3_up", "k1", "concat_half", "ragged"])
+@pytest.mark.parametrize("case", ["k3", "k3_s2", "k3_up", "k1", "concat_half", "ragged", "big_k3", "big_up", "big_k1", "big_concat", "big_short",
+                                  "big_one_row"])
 def test_conv_weight_gradient(dt, case):
     """dW of nn.Conv1d from autograd, for every source map the forward conv supports."""
     engine, _lib = _eng()
@@ -101,6 +102,18 @@ def test_conv_weight_gradient(dt, case):
         ci_off, cin_total = 64, 128 + 64 + 32   # this source is channels 64..191 of a wider (concatenated) conv input
     elif case == "ragged":
         B, L, Ci, Co = 5, 13, 40, 72
+    elif case == "big_k3":          # big_*: shapes the 128 x 128 x all-taps kernel takes (fp32 only; bf16 stays on the small-tile kernel)
+        Ci, Co = 128, 256
+    elif case == "big_up":
+        L, up, Ci, Co = 25, 50, 256, 128
+    elif case == "big_k1":
+        k, Ci, Co = 1, 256, 256
+    elif case == "big_concat":
+        Ci, Co, ci_off, cin_total = 128, 128, 128, 384
+    elif case == "big_short":       # several trajectory boundaries inside every 32-row chunk
+        B, L, Ci, Co = 70, 13, 128, 128
+    elif case == "big_one_row":     # the embedding MLP's linears: lout = 1, every row is first and last of its trajectory
+        B, L, Ci, Co, k = 100, 1, 128, 256, 1
     cin_total = cin_total or Ci
     x = torch.randn(B, Ci, L, generator=g)
     xq = q(x, dt)
@@ -114,7 +127,7 @@ def test_conv_weight_gradient(dt, case):
     src, dyr = rows(x, dt), rows(dy, dt)
     seg = _lib.KSeg(src.data_ptr(), float(L) / up if up else 0.0, 0, Ci, 0, Ci, k, stride, L, up or L, 0)
     dw = torch.full((Co, cin_total, k), 0.5, device="cuda")
-    ws = workspace(64 * Co * Ci * k)
+    ws = workspace((512 if case.startswith("big") else 64) * Co * Ci * k)
     for acc in (0, 1):
         _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, dw.data_ptr(), cin_total, ci_off, acc,
                                              _lib.dtype_code(dt), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
@@ -123,6 +136,15 @@ def test_conv_weight_gradient(dt, case):
     untouched = torch.ones(cin_total, dtype=torch.bool)
     untouched[ci_off:ci_off + Ci] = False
     assert bool((dw.cpu()[:, untouched, :] == 0.5).all())
+    if case.startswith("big") and dt == torch.float32:     # and bit-for-bit repeatable; the small-tile kernel agrees to rounding
+        again = torch.empty_like(dw)
+        for force, tol in ((0, 0.0), (1, 2e-5)):
+            old = _lib.lib().tdx_conv_wgrad_debug(force)
+            _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, again.data_ptr(), cin_total, ci_off, 0,
+                                                 _lib.dtype_code(dt), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            _lib.lib().tdx_conv_wgrad_debug(old)
+            a, b = again.cpu()[:, ci_off:ci_off + Ci, :], dw.cpu()[:, ci_off:ci_off + Ci, :] / 2
+            assert rel(a, b) <= tol, force
     small = workspace(Co * Ci * k)   # room for a single slab: still correct
     _lib.check(_lib.lib().tdx_conv_wgrad(dyr.data_ptr(), Co, 0, Co, ctypes.byref(seg), B, lout, dw.data_ptr(), cin_total, ci_off, 0,
                                          _lib.dtype_code(dt), small.data_ptr(), small.numel(), _lib.stream_ptr()))

@@ -117,6 +117,48 @@ def test_two_process_shard_and_gather_equals_unsharded(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from trajectorydiffusion_amd.distributed import shard_bounds, allreduce_mean_
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# the data-parallel training step on a stand-in model: equal shards of one global batch, MSE 'mean' loss per shard
+# (train.ipynb:200), gradient mean over ranks == the full-batch gradient
+torch.manual_seed(5)
+Bg, n_in, n_out = 8, 37, 29
+W = torch.randn(n_out, n_in, dtype=torch.float64, requires_grad=True); b = torch.randn(n_out, dtype=torch.float64, requires_grad=True)
+x = torch.randn(Bg, n_in, dtype=torch.float64); y = torch.randn(Bg, n_out, dtype=torch.float64)
+loss = lambda xs, ys: torch.nn.functional.mse_loss(torch.tanh(xs @ W.T + b), ys)
+gW, gb = torch.autograd.grad(loss(x, y), (W, b))
+full = torch.cat([gW.flatten(), gb.flatten()])
+lo, hi = shard_bounds(Bg, rank, world)
+mW, mb = torch.autograd.grad(loss(x[lo:hi], y[lo:hi]), (W, b))
+flat = torch.cat([mW.flatten(), mb.flatten()]).contiguous()
+allreduce_mean_(flat, bucket_bytes=1000)          # 125-element slices: 9 buckets, the last one ragged
+assert torch.allclose(flat, full, rtol=1e-12, atol=1e-14), (rank, (flat - full).abs().max())
+f32 = torch.arange(1001, dtype=torch.float32) * (rank + 1)
+allreduce_mean_(f32, bucket_bytes=64 << 20)       # one bucket
+assert torch.equal(f32, torch.arange(1001, dtype=torch.float32) * 1.5)
+try:
+    allreduce_mean_(torch.zeros(4, 4))
+    raise SystemExit("2-D buffer accepted")
+except ValueError:
+    pass
+dist.barrier(); dist.destroy_process_group(); print("rank", rank, "ok")
+'''
+
+
+def test_two_process_gradient_mean_equals_full_batch_gradient(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29573", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_persistent_conv_kernels_have_no_spills_in_their_k_loops():
     """Build check (cross-compiles conv_gemm.hip for gfx950, no GPU needed): a spill reload inside a K loop is a vector-memory
     operation whose wait also waits for every LDS-DMA in flight, which would serialise the software pipeline."""

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "tdx_mse_loss_grad": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tdx_colsum": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "tdx_conv_wgrad_debug": (_i32, [_i32]),
     "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
                                      _i32, _i32, _vp]),
     "tdx_interleave2": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -1,12 +1,15 @@
 // Training-step building blocks (train.ipynb:198-209): eps-MSE loss and its gradient, column sums
 // (bias gradients), convolution weight gradients, GroupNorm(+Swish) backward, fused AdamW.  fp32 arithmetic throughout;
 // every reduction has a fixed order (two stages through a caller-provided workspace, no atomics): results are bitwise
-// reproducible.  The step itself (saved activations, backward program, DDP all-reduce) is not assembled yet.
+// reproducible.  The step itself (saved activations, backward program) is assembled in trajectorydiffusion_amd/training.py.
+#include <algorithm>
+
 #include "tdx_common.h"
 
 namespace {
 
-constexpr int kRedBlocks = 1024;  // first-stage partials of the scalar / column reductions
+constexpr int kRedBlocks = 1024;
+int g_wgrad_force = 0;  // tests: bit 0 = never take the large-tile weight-gradient kernel  // first-stage partials of the scalar / column reductions
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {  // fixed-order tree: lanes, then the four waves
   v = wave_sum(v);
@@ -148,6 +151,123 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       if (co < p.cout && ci < p.cin) p.part[((size_t)split * p.cout + co) * kdim + ci * p.taps + tap] = acc[j][r];
     }
   }
+#endif
+}
+
+// The large-tile variant for the shapes that carry the FLOPs (fp32, stride 1, cout and cin multiples of 128): a 64 x 64 tile
+// of one tap re-reads dY and X from L2 at 16 flop/B, more than the caches can feed the fp32 MFMA pipe with.  Here one
+// 512-thread workgroup owns 128 co x 128 ci x ALL taps: the chunk's X rows are staged once as a (32 + 2)-row window that
+// the three taps read at row offsets 0/1/2 (96 flop/B), with per-row flags masking the rows that belong to the neighbouring
+// trajectory.  Each of the 8 waves holds 64 co x 32 ci x TAPS accumulators (96 VGPRs); the next chunk's global loads are
+// in flight (registers) while the current chunk is multiplied.  Rows are VIRTUAL rows (b, u) of the nearest-upsampled
+// source, mapped to stored rows by the loader, so upsampled sources take this path too.
+template <int TAPS>
+__global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RC = 32, PAD = TAPS == 3 ? 1 : 0, WR = RC + 2 * PAD, LD = 144;  // 144 mod 64 = 16: the 4 k rows hit disjoint banks
+  constexpr int XV = (WR * 32 + 511) / 512;                                     // float4 loads of the X window per thread
+  __shared__ __attribute__((aligned(16))) float dys[RC * LD];
+  __shared__ __attribute__((aligned(16))) float xs[WR * LD];
+  __shared__ int flags[WR];                                                      // bit 0: first row of a trajectory, bit 1: last
+  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 128, split = blockIdx.z;
+  const int r_begin = split * p.rows_per_split, r_end = min(p.N, r_begin + p.rows_per_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cob = (wave & 1) * 64, cib = (wave >> 1) * 32;
+  const int l16 = lane & 15, lk = lane >> 4;
+  const float* dy = reinterpret_cast<const float*>(p.dy) + p.dy_off + co0;
+  const float* x = reinterpret_cast<const float*>(p.x) + p.x_off + ci0;
+  f32x4 acc[TAPS][4][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 dreg[2], xreg[XV];
+  int freg = 0;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // dY chunk: 32 rows x 32 float4
+      const int e = tid + q * 512, row = e >> 5, c4 = (e & 31) * 4;
+      const int n = r0 + row;
+      dreg[q] = n < r_end ? *reinterpret_cast<const f32x4*>(dy + (size_t)n * p.dy_ld + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < XV; ++q) {  // X window: WR virtual rows x 32 float4
+      const int e = tid + q * 512, row = e >> 5, c4 = (e & 31) * 4;
+      const int m = r0 - PAD + row;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < WR && m >= 0 && m < p.N) {
+        const int b = m / p.lvirt, u = m - b * p.lvirt;
+        const int srow = p.up_scale > 0.f ? min((int)floorf((float)u * p.up_scale), p.lin - 1) : u;
+        v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * p.lin + srow) * p.x_ld + c4);
+      }
+      xreg[q] = v;
+    }
+    if (tid < WR) {
+      const int m = r0 - PAD + tid;
+      const int u = m >= 0 ? m % p.lvirt : 0;
+      freg = (u == 0 ? 1 : 0) | (u == p.lvirt - 1 ? 2 : 0);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * 512;
+      *reinterpret_cast<f32x4*>(&dys[(e >> 5) * LD + (e & 31) * 4]) = dreg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < XV; ++q) {
+      const int e = tid + q * 512;
+      if ((e >> 5) < WR) *reinterpret_cast<f32x4*>(&xs[(e >> 5) * LD + (e & 31) * 4]) = xreg[q];
+    }
+    if (tid < WR) flags[tid] = freg;
+  };
+
+  if (r_begin < r_end) fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += RC) {
+    stash();
+    __syncthreads();
+    if (r0 + RC < r_end) fetch(r0 + RC);
+#pragma unroll
+    for (int k4 = 0; k4 < RC / 4; ++k4) {
+      const int kr = k4 * 4 + lk;
+      float a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = dys[kr * LD + cob + i * 16 + l16];
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int wr = kr + t;  // window row of the source row that output row kr reads through tap t
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = xs[wr * LD + cib + j * 16 + l16];
+        if (TAPS == 3 && t != 1) {
+          const bool dead = (flags[wr] & (t == 0 ? 2 : 1)) != 0;  // tap 0 never reads a trajectory's last row, tap 2 never its first
+          bv[0] = dead ? 0.f : bv[0];
+          bv[1] = dead ? 0.f : bv[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[t][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // acc[t][i][j][r] = dW[co0 + cob + 16 i + 4 (lane >> 4) + r][ci0 + cib + 16 j + (lane & 15)][t]
+  const int kdim = p.cin * TAPS;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + cob + i * 16 + 4 * lk + r, ci = ci0 + cib + j * 16 + l16;
+          p.part[((size_t)split * p.cout + co) * kdim + ci * TAPS + t] = acc[t][i][j][r];
+        }
 #endif
 }
 
@@ -540,17 +660,31 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   TDX_CHECK_ARG(ci_off >= 0 && ci_off + s.cin <= cin_total, "tdx_conv_wgrad: ci_off/cin_total do not fit");
   const int N = B * lout;
   const int64_t per_split = (int64_t)cout * s.cin * s.taps;
-  int splits = (N + 2047) / 2048;
-  if (splits > 64) splits = 64;
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = !(g_wgrad_force & 1) && dtype == TDX_F32 && s.stride == 1 && cout % 128 == 0 && s.cin % 128 == 0 && dy_ld % 4 == 0 &&
+                   dy_off % 4 == 0 && s.src_ld % 4 == 0 && s.ch_off % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)s.src & 15) == 0;
+  int splits;
+  if (big) {  // one 512-thread workgroup per CU: aim at two full rounds of the 256 CUs
+    const int tiles = (cout / 128) * (s.cin / 128);
+    splits = std::max(1, 512 / tiles);
+    splits = std::min(splits, (N + 31) / 32);
+  } else {
+    splits = std::min(64, (N + 2047) / 2048);
+  }
   if ((int64_t)splits * per_split > ws_floats) splits = (int)(ws_floats / per_split);
   TDX_CHECK_ARG(splits >= 1, "tdx_conv_wgrad: workspace of %lld floats is smaller than one gradient (%lld)", (long long)ws_floats, (long long)per_split);
   WgradArgs a{(const char*)dy, (const char*)s.src, dy_ld, dy_off, cout, s.src_ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt,
               s.lvirt != s.lin ? s.up_scale : 0.f, N, lout, ((N + splits - 1) / splits + 31) / 32 * 32, ws};
   splits = (N + a.rows_per_split - 1) / a.rows_per_split;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)(((s.cin + 63) / 64) * s.taps), (unsigned)splits);
-  if (dtype == TDX_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
+  if (big) {
+    const dim3 grid((unsigned)(cout / 128), (unsigned)(s.cin / 128), (unsigned)splits);
+    if (s.taps == 3) hipLaunchKernelGGL(conv_wgrad_big_kernel<3>, grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_big_kernel<1>, grid, dim3(512), 0, st, a);
+  } else {
+    const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)(((s.cin + 63) / 64) * s.taps), (unsigned)splits);
+    if (dtype == TDX_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, st, ws, splits, cout, s.cin, s.taps, dw,
                      cin_total, ci_off, accumulate);
   TDX_CHECK_LAUNCH("conv_wgrad");
@@ -683,4 +817,10 @@ extern "C" int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, 
                      1.0f / (1.0f - p), seed, layer, step_ctr);
   TDX_CHECK_LAUNCH("dropout_kernel");
   return TDX_OK;
+}
+
+extern "C" int tdx_conv_wgrad_debug(int32_t force) {
+  const int old = g_wgrad_force;
+  g_wgrad_force = force;
+  return old;
 }

@@ -1,4 +1,5 @@
-"""Batch sharding for multi-GPU sampling: one process per GPU, no data-path collective, one final gather.
+"""Batch sharding for multi-GPU sampling: one process per GPU, no data-path collective, one final gather; and the one real
+exchange step of the training path, the data-parallel gradient mean.
 
 Trajectories are independent given the weights (reference DiffusionManager.py:57-79), so rank r of n samples
 the contiguous slice shard_bounds(B, r, n) and passes first_sample=lo so that in-kernel Philox noise is keyed
@@ -41,3 +42,27 @@ def sample_sharded(dm, model, x_T: torch.Tensor, cat_attr: torch.Tensor, num_att
     lo, hi = shard_bounds(x_T.shape[0], rank, world)
     x0 = dm.diffusionBackward(x_T[lo:hi], cat_attr[lo:hi], num_attr[lo:hi], model, first_sample=lo, **kw)
     return gather_samples(x0, x_T.shape[0])
+
+
+def allreduce_mean_(flat: torch.Tensor, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 64 << 20) -> torch.Tensor:
+    """In-place mean over ranks of one flat gradient buffer, issued as back-to-back asynchronous all-reduces over
+    bucket_bytes-sized slices (no packing: TrainStep keeps every parameter gradient inside one flat buffer).
+
+    xGMI is point-to-point, so RCCL's ring all-reduce is bound per link (~153 GB/s); the default 64 MiB slices are large
+    enough to run at link rate and small enough that the reduction of slice k+1 overlaps the scaling of slice k.  The mean
+    (not the sum) matches what torch's DistributedDataParallel hands the optimizer, so lr keeps its single-GPU meaning."""
+    if flat.dim() != 1 or not flat.is_contiguous():
+        raise ValueError("allreduce_mean_: expected one contiguous 1-D buffer")
+    world = dist.get_world_size(group)
+    if world == 1 or flat.numel() == 0:
+        return flat
+    step = max(1, bucket_bytes // flat.element_size())
+    pending = []
+    for lo in range(0, flat.numel(), step):
+        piece = flat[lo:lo + step]
+        pending.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True), piece))
+    inv = 1.0 / world
+    for work, piece in pending:
+        work.wait()
+        piece.mul_(inv)
+    return flat

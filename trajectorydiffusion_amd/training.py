@@ -58,6 +58,10 @@ class TrainStep:
             if p.dtype != torch.float32 or p.device.type != "cuda" or not p.is_contiguous():
                 raise TdxError(f"TrainStep: parameter {n} must be a contiguous fp32 tensor on the GPU")
         self.grads: Dict[str, torch.Tensor] = {}    # parameter name -> gradient (only parameters the forward pass uses)
+        # parameter gradients are views into ONE flat buffer (64-float aligned), handed out in first-use order: one memset
+        # per step, and the data-parallel all-reduce (distributed.allreduce_mean_) runs over it in place with no packing copies
+        self._garena = torch.zeros(sum((p.numel() + 63) // 64 * 64 for p in self.params.values()), device=device, dtype=torch.float32)
+        self._garena_used = 0
         self._pname = {id(p): n for n, p in self.params.items()}
         self._padded: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Tuple[slice, ...]]] = []
         self.ws = torch.empty(64 * 1024 * 1024 * 3 + 16, device=device, dtype=torch.float32)   # wgrad slabs (largest: 1024 x 1024 x 3)
@@ -90,8 +94,22 @@ class TrainStep:
             raise TdxError("TrainStep: unknown parameter")
         g = self.grads.get(n)
         if g is None:
-            g = self.grads[n] = self._new(*p.shape)
+            g = self.grads[n] = self._param_grad(n, p) if n in self.params else self._new(*p.shape)
         return g
+
+    def _param_grad(self, n: str, p: torch.Tensor) -> torch.Tensor:
+        lo = self._garena_used
+        self._garena_used = lo + (p.numel() + 63) // 64 * 64
+        return self._garena[lo:lo + p.numel()].view(p.shape)
+
+    def flat_gradients(self) -> torch.Tensor:
+        """Every parameter gradient as one flat fp32 tensor (the views in self.grads alias it)."""
+        return self._garena[: self._garena_used]
+
+    def sync_gradients(self, group=None, bucket_bytes: int = 64 << 20) -> None:
+        """Data-parallel mean of the gradients over the ranks of `group` (RCCL all-reduce over xGMI), in place."""
+        from .distributed import allreduce_mean_
+        allreduce_mean_(self.flat_gradients(), group=group, bucket_bytes=bucket_bytes)
 
     def _pad(self, p: torch.Tensor, shape: Sequence[int], where: Tuple[slice, ...]) -> torch.Tensor:
         """A zero-padded copy of parameter p (channel counts the GEMM kernels can take), refreshed every step; its gradient is
@@ -364,8 +382,10 @@ class TrainStep:
         with torch.no_grad():
             for g in self._agrad.values():
                 g.zero_()
-            for g in self.grads.values():
-                g.zero_()
+            self.flat_gradients().zero_()
+            for n, g in self.grads.items():
+                if n not in self.params:
+                    g.zero_()
             self.G(self.out4)[:, :, :2].copy_(dpred.permute(0, 2, 1))
             self.bw.run()
             for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters
@@ -374,7 +394,7 @@ class TrainStep:
                     continue
                 gp = self.grads.get(self._pname[id(p)])
                 if gp is None:
-                    gp = self.grads[self._pname[id(p)]] = self._new(*p.shape)
+                    gp = self.PG(p)
                 gp.add_(gq[where].reshape(p.shape) if where is not None else gq.reshape(p.shape))
         return self.named_gradients()
 

@@ -73,6 +73,7 @@ class TrainStep:
         self.rng = torch.zeros(4, dtype=torch.int32, device=device)   # [0] = forward-pass counter, read by tdx_dropout
         self._passes = 0
         self._layer = 0
+        self._repack_graph, self._repack_key = None, None
         self._build()
 
     # ---- bookkeeping -----------------------------------------------------------------------------------------------------
@@ -348,6 +349,23 @@ class TrainStep:
         self.conv(name, [_Src(src, k, 1, W, taps=1, needs_grad=needs_grad)], W.shape[0], 1, out, out_off=off, biases=[mod.bias], act=act)
 
     # ---- one step -----------------------------------------------------------------------------------------------------------
+    def _refresh_packed_weights(self) -> None:
+        """Re-derive the GEMM-layout copies (forward, flipped/transposed for the data gradients, padded stand-ins) from the
+        parameters' current values.  ~200 small layout ops: launch-bound when issued one by one, so they are captured once
+        into a HIP graph and replayed; the capture is redone if a parameter's storage has moved."""
+        key = tuple(p.data_ptr() for p in self.params.values())
+        if self._repack_graph is None or self._repack_key != key:
+            for f in self._repack:                      # eager once: warms the allocator and makes the copies valid now
+                f()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for f in self._repack:
+                    f()
+            self._repack_graph, self._repack_key = g, key
+        else:
+            self._repack_graph.replay()
+
     def forward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor) -> torch.Tensor:
         """eps_hat (B, 2, L) of the training-mode forward pass; activations stay saved for backward()."""
         m, B, L = self.m, self.B, self.L
@@ -356,12 +374,12 @@ class TrainStep:
             raise TdxError(f"TrainStep: expected x_t of shape {(B, 2, L)}, got {tuple(x_t.shape)}")
         for v in (x_t, t, cat, num):
             _lib.require_device(v, "TrainStep input")
-        if int(t.min()) < 0 or int(t.max()) >= emb.pos_enc.shape[0] or int(cat[:, :4].min()) < 0 or int(cat[:, :4].max()) > 255 or \
-                int(cat[:, 4].min()) < 0 or int(cat[:, 4].max()) > 32:
+        bad = (t.min() < 0) | (t.max() >= emb.pos_enc.shape[0]) | (cat[:, :4].min() < 0) | (cat[:, :4].max() > 255) | (cat[:, 4].min() < 0) | \
+            (cat[:, 4].max() > 32)
+        if bool(bad):                                   # the step's only host synchronisation
             raise IndexError("TrainStep: time step or categorical attribute out of range")
         with torch.no_grad():
-            for f in self._repack:
-                f()
+            self._refresh_packed_weights()
             self._passes += 1
             self.rng[0] = self._passes
             # plumbing: layouts and embedding-row gathers

@@ -8,6 +8,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt 
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph > $O/fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph > $O/write.log 2>&1
 find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+timeout -k 10 200 python scripts/train_bench.py --breakdown > $O/train_bench.json 2> $O/train_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python3 scripts/train_bench.py --no-graph --steps 2 --warmup 1 > $O/ktt.log 2>&1
+find $O/ktt -name "*kernel_stats.csv" -exec cp {} $O/train_kernel_stats.csv \;
+rm -rf $O/ktt
 find $O/fetch -name "*counter_collection.csv" -exec cp {} $O/fetch.csv \;
 find $O/write -name "*counter_collection.csv" -exec cp {} $O/write.csv \;
 rm -rf $O/kt $O/fetch $O/write

@@ -37,6 +37,17 @@ def test_state_dict_keys_match_reference_and_default_init_is_deterministic(golde
         TrajUNet([128, 128], res_blocks=1)
 
 
+def test_checkpoint_is_plain_tensors(tmp_path):
+    """saveModel / loadModel (Utils.py:6-12): the file must hold tensors only, loadable with weights_only=True, strict keys."""
+    import torch
+    from trajectorydiffusion_amd import TrajUNet
+    m = TrajUNet([16, 16, 32], diffusion_steps=20, res_blocks=1) if False else TrajUNet([128, 128, 256, 512, 1024], diffusion_steps=500, res_blocks=2)
+    path = tmp_path / "TrajUNet_0.pth"
+    torch.save(m.state_dict(), path)
+    sd = torch.load(path, weights_only=True)
+    assert list(sd) == list(m.state_dict()) and m.load_state_dict(sd).missing_keys == []
+
+
 def test_no_cpu_fallback():
     from trajectorydiffusion_amd import DiffusionManager, TrajUNet
     from trajectorydiffusion_amd._lib import TdxError

@@ -202,12 +202,12 @@ class TrajUNet(_HipBlock):
             for j in range(self.res_blocks - 1):
                 yield f"up_blocks.{i}.{j}.", self.up_blocks[i][j]
 
-    def _version(self) -> int:
+    def _weights_version(self) -> int:   # (not "_version": nn.Module keeps its state_dict format version under that name)
         return sum(p._version for p in self.parameters())
 
     def packed_weights(self, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
         """GEMM-layout weights in the compute dtype, rebuilt whenever a parameter changes."""
-        ver = self._version()
+        ver = self._weights_version()
         hit = self._packed.get(dtype)
         if hit is not None and hit[0] == ver:
             return hit[1]

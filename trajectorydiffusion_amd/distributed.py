@@ -57,6 +57,13 @@ def allreduce_mean_(flat: torch.Tensor, group: Optional[dist.ProcessGroup] = Non
     if world == 1 or flat.numel() == 0:
         return flat
     step = max(1, bucket_bytes // flat.element_size())
+    if flat.is_cuda and dist.get_backend(group) != "nccl":
+        # rehearsal path (gloo has no device collectives worth relying on): stage each slice through the host, synchronously
+        for lo in range(0, flat.numel(), step):
+            host = flat[lo:lo + step].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat[lo:lo + step].copy_(host.mul_(1.0 / world))
+        return flat
     pending = []
     for lo in range(0, flat.numel(), step):
         piece = flat[lo:lo + step]

@@ -41,7 +41,7 @@ class _Src:
 
 class TrainStep:
     def __init__(self, model, B: int, L: int, device: torch.device, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: int = 0):
+                 eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: int = 0, graph_repack: bool = True):
         self.m, self.B, self.L, self.dev = model, B, L, device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lib = _lib.lib()
@@ -73,7 +73,7 @@ class TrainStep:
         self.rng = torch.zeros(4, dtype=torch.int32, device=device)   # [0] = forward-pass counter, read by tdx_dropout
         self._passes = 0
         self._layer = 0
-        self._repack_graph, self._repack_key = None, None
+        self._repack_graph, self._repack_key, self._graph_repack = None, None, graph_repack   # (rocprofv3 cannot trace a capture)
         self._build()
 
     # ---- bookkeeping -----------------------------------------------------------------------------------------------------
@@ -353,6 +353,10 @@ class TrainStep:
         """Re-derive the GEMM-layout copies (forward, flipped/transposed for the data gradients, padded stand-ins) from the
         parameters' current values.  ~200 small layout ops: launch-bound when issued one by one, so they are captured once
         into a HIP graph and replayed; the capture is redone if a parameter's storage has moved."""
+        if not self._graph_repack:
+            for f in self._repack:
+                f()
+            return
         key = tuple(p.data_ptr() for p in self.params.values())
         if self._repack_graph is None or self._repack_key != key:
             for f in self._repack:                      # eager once: warms the allocator and makes the copies valid now
@@ -439,6 +443,7 @@ class TrainStep:
             mm, vv = self.state[n]
             _lib.check(self.lib.tdx_adamw_step(p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), self.lr, self.betas[0],
                                                self.betas[1], self.eps, self.wd, self.step_count, st), "tdx_adamw_step")
+            torch.autograd.graph.increment_version(p)   # the inference side re-packs its weights when a parameter's version moves
 
 
 class _TrainForward(torch.autograd.Function):

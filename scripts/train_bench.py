@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--breakdown", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="weight re-layout ops launched eagerly (needed under rocprofv3 --kernel-trace)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--overlap", action="store_true", help="N > 1: reduce gradient slices under the backward program instead of after it")
+    ap.add_argument("--check-overlap", action="store_true", help="N > 1: assert that both reduction schedules give identical gradients")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,9 +68,12 @@ def main():
 
     def step():
         x_t = dm.diffusionForward(x0, t, eps)
-        loss = ts.forward_backward(x_t, t, cat, num, eps)
-        if world > 1:
-            ts.sync_gradients()
+        if world > 1 and a.overlap:
+            loss = ts.forward_backward(x_t, t, cat, num, eps, sync_group=None)
+        else:
+            loss = ts.forward_backward(x_t, t, cat, num, eps)
+            if world > 1:
+                ts.sync_gradients()
         ts.optimizer_step()
         return loss
 
@@ -99,6 +104,21 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "replicas diverged"
 
+    if world > 1 and a.check_overlap:
+        x_t = dm.diffusionForward(x0, t, eps)
+        ts._passes = 1000                                   # replay the same dropout masks in both passes
+        ts.forward_backward(x_t, t, cat, num, eps)
+        local = ts.flat_gradients().clone()
+        ts.sync_gradients()
+        after = ts.flat_gradients().clone()
+        ts._passes = 1000
+        ts.forward(x_t, t, cat, num)                        # dpred of the pass above is still in ts.dpred (same inputs, same masks)
+        ts.backward(ts.dpred, sync_group=None, bucket_bytes=3 << 20)   # many small slices: exercises the readiness plan
+        assert torch.equal(ts.flat_gradients(), after), "overlapped reduction differs from reduce-after-backward"
+        assert not torch.equal(local, after), "ranks hold different data, the mean must differ from the local gradient"
+        plan = ts._bucket_plan(3 << 20)
+        print(f"rank {rank}: overlap check ok, {len(plan)} slices, first ready after launch {plan[0][2]} of {len(ts.bw.ops)}", file=sys.stderr, flush=True)
+
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     x_t = dm.diffusionForward(x0, t, eps)
     ev[0].record()
@@ -112,7 +132,7 @@ def main():
     out = {"metric": "training steps/sec, TrajUNet fp32 step (forward+backward+AdamW), L=%d" % L, "value": round(1 / el, 4), "unit": "steps/s",
            "trajectories_per_s": round(world * B / el, 2), "ms_per_step": round(1e3 * el, 2), "n_gpus": world, "scaling": "weak", "steps": a.steps, "warmup": a.warmup,
            "dtype": "fp32", "data": "synthetic", "config": {"workload": f"C4: TrajUNet training step, B={B} per GPU, L={L}, schedule {SCHEDULE}, dropout 0.1, AdamW",
-                      "parallelism": f"data parallel x{world}, gradient mean over {a.backend if world > 1 else 'nothing'}"},
+                      "parallelism": f"data parallel x{world}, gradient mean over {a.backend if world > 1 else 'nothing'}" + (", overlapped with backward" if a.overlap and world > 1 else "")},
            "forward_ms": round(ev[0].elapsed_time(ev[1]), 2), "backward_ms": round(ev[1].elapsed_time(ev[2]), 2),
            "optimizer_ms": round(ev[2].elapsed_time(ev[3]), 2),
            "model_tflops_per_gpu": round(3 * FLOP_PER_TRAJ_FWD * B / el / 1e12, 2), "peak_tflops_fp32_mfma": 157.3,

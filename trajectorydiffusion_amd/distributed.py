@@ -57,19 +57,22 @@ def allreduce_mean_(flat: torch.Tensor, group: Optional[dist.ProcessGroup] = Non
     if world == 1 or flat.numel() == 0:
         return flat
     step = max(1, bucket_bytes // flat.element_size())
-    if flat.is_cuda and dist.get_backend(group) != "nccl":
-        # rehearsal path (gloo has no device collectives worth relying on): stage each slice through the host, synchronously
-        for lo in range(0, flat.numel(), step):
-            host = flat[lo:lo + step].cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            flat[lo:lo + step].copy_(host.mul_(1.0 / world))
-        return flat
-    pending = []
-    for lo in range(0, flat.numel(), step):
-        piece = flat[lo:lo + step]
-        pending.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True), piece))
+    pending = [allreduce_slice_async(flat[lo:lo + step], group) for lo in range(0, flat.numel(), step)]
     inv = 1.0 / world
-    for work, piece in pending:
-        work.wait()
-        piece.mul_(inv)
+    for work, lo in zip(pending, range(0, flat.numel(), step)):
+        if work is not None:
+            work.wait()
+        flat[lo:lo + step].mul_(inv)
     return flat
+
+
+def allreduce_slice_async(piece: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+    """Start the in-place SUM over ranks of one slice on the CURRENT stream's timeline; returns the work handle to wait on
+    (None when the reduction has already completed).  RCCL for device tensors; any other backend (the gloo rehearsals of
+    the tests) stages the slice through the host, synchronously: gloo's own device path hung on this image."""
+    if piece.is_cuda and dist.get_backend(group) != "nccl":
+        host = piece.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        piece.copy_(host)
+        return None
+    return dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True)

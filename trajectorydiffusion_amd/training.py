@@ -73,6 +73,8 @@ class TrainStep:
         self.rng = torch.zeros(4, dtype=torch.int32, device=device)   # [0] = forward-pass counter, read by tdx_dropout
         self._passes = 0
         self._layer = 0
+        self._plans: Dict[int, List[Tuple[int, int, int]]] = {}
+        self._comm_stream = None
         self._repack_graph, self._repack_key, self._graph_repack = None, None, graph_repack   # (rocprofv3 cannot trace a capture)
         self._build()
 
@@ -337,6 +339,53 @@ class TrainStep:
         self.pred = self._new(B, 2, L)
         self.dpred = self._new(B, 2, L)
         self.loss = self._new(1)
+        for q, p, _, where in self._padded:          # folded targets get their slice of the flat buffer now, not at the first backward
+            if self._pname[id(q)] in self.grads:
+                self.PG(p)
+        self._grad_ready = self._scan_gradient_writers()
+
+    def _scan_gradient_writers(self) -> Dict[str, int]:
+        """name -> index of the LAST backward launch that writes that parameter's gradient (len(ops) for gradients that
+        are completed by the fold of a padded stand-in after the program).  Found by looking for pointers into the flat
+        gradient buffer among the launch arguments, so it cannot drift from what the program really does."""
+        base, end = self._garena.data_ptr(), self._garena.data_ptr() + 4 * self._garena_used
+        spans = sorted((g.data_ptr(), g.data_ptr() + 4 * g.numel(), n) for n, g in self.grads.items() if n in self.params)
+        starts = [lo for lo, _, _ in spans]
+        ready = {n: -1 for _, _, n in spans}
+        import bisect
+        for i, (_, _, args) in enumerate(self.bw.ops):
+            for a in args:
+                if isinstance(a, int) and base <= a < end:
+                    k = bisect.bisect_right(starts, a) - 1
+                    if k >= 0 and a < spans[k][1]:
+                        ready[spans[k][2]] = i
+        nops = len(self.bw.ops)
+        for q, p, _, where in self._padded:
+            if self._pname[id(q)] in self.grads:
+                ready[self._pname[id(p)]] = nops
+        missing = [n for n, r in ready.items() if r < 0]
+        if missing:
+            raise TdxError(f"TrainStep: no backward launch writes the gradient of {missing[:3]}")
+        return ready
+
+    def _bucket_plan(self, bucket_bytes: int) -> List[Tuple[int, int, int]]:
+        """(lo, hi, ready) slices of the flat gradient buffer, at most bucket_bytes each, in the order they complete.  The
+        buffer is laid out in backward order, so consecutive slices complete one after the other while the program runs."""
+        key = int(bucket_bytes)
+        plan = self._plans.get(key)
+        if plan is None:
+            step = max(64, bucket_bytes // 4)
+            base = self._garena.data_ptr()
+            spans = sorted(((g.data_ptr() - base) // 4, (g.data_ptr() - base) // 4 + g.numel(), self._grad_ready[n])
+                           for n, g in self.grads.items() if n in self.params)
+            plan = []
+            for lo in range(0, self._garena_used, step):
+                hi = min(lo + step, self._garena_used)
+                rdy = max((r for a, b, r in spans if a < hi and b > lo), default=0)
+                plan.append((lo, hi, rdy))
+            plan.sort(key=lambda t: (t[2], t[0]))
+            self._plans[key] = plan
+        return plan
 
     def _lin(self, name: str, src: torch.Tensor, k: int, mod, out: torch.Tensor, off: int, act: int, W: Optional[torch.Tensor] = None,
              needs_grad: bool = True) -> None:
@@ -399,8 +448,15 @@ class TrainStep:
             self.pred.copy_(self.out4[:, :, :2].permute(0, 2, 1))
         return self.pred
 
-    def backward(self, dpred: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Gradients of every used parameter (by name) for the gradient dpred (B, 2, L) of the last forward()'s output."""
+    def backward(self, dpred: torch.Tensor, sync_group=False, bucket_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
+        """Gradients of every used parameter (by name) for the gradient dpred (B, 2, L) of the last forward()'s output.
+
+        sync_group (None = the default process group, or a group): data parallel.  The mean over ranks of each
+        bucket_bytes slice of the flat gradient buffer is started on a side stream as soon as the backward launch that
+        completes the slice has been issued, so the RCCL all-reduces run under the rest of the backward program; on return
+        the gradients are the means (what backward() followed by sync_gradients() gives; bit for bit at world size 2, where
+        the order of the sum is fixed)."""
+        sync = sync_group is not False
         with torch.no_grad():
             for g in self._agrad.values():
                 g.zero_()
@@ -409,24 +465,61 @@ class TrainStep:
                 if n not in self.params:
                     g.zero_()
             self.G(self.out4)[:, :, :2].copy_(dpred.permute(0, 2, 1))
-            self.bw.run()
-            for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters
-                gq = self.grads.get(self._pname[id(q)])
-                if gq is None:
-                    continue
-                gp = self.grads.get(self._pname[id(p)])
-                if gp is None:
-                    gp = self.PG(p)
-                gp.add_(gq[where].reshape(p.shape) if where is not None else gq.reshape(p.shape))
+            if not sync:
+                self.bw.run()
+                self._fold_padded()
+                return self.named_gradients()
+            import torch.distributed as dist
+            from .distributed import allreduce_slice_async
+            world = dist.get_world_size(sync_group)
+            plan = self._bucket_plan(bucket_bytes) if world > 1 else []
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.dev)
+            main, comm, flat = torch.cuda.current_stream(), self._comm_stream, self._garena
+            pending, k = [], 0
+
+            def start_ready(done: int) -> None:   # every slice whose last writer has index <= done
+                nonlocal k
+                if k < len(plan) and plan[k][2] <= done:
+                    comm.wait_stream(main)        # orders the collective after the launches issued so far, not after later ones
+                    while k < len(plan) and plan[k][2] <= done:
+                        lo, hi, _ = plan[k]
+                        with torch.cuda.stream(comm):
+                            pending.append((allreduce_slice_async(flat[lo:hi], sync_group), lo, hi))
+                        k += 1
+            st = _lib.stream_ptr()
+            for i, (name, fn, args) in enumerate(self.bw.ops):
+                rc = fn(*args, st)
+                if rc:
+                    _lib.check(rc, name)
+                start_ready(i)
+            self._fold_padded()
+            start_ready(len(self.bw.ops))
+            for work, lo, hi in pending:
+                if work is not None:
+                    work.wait()                   # main stream waits for the collective
+            main.wait_stream(comm)
+            if world > 1:
+                flat[: self._garena_used].mul_(1.0 / world)
         return self.named_gradients()
 
-    def forward_backward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
-        """Loss (device scalar) and gradients (self.grads, by parameter name) of mean((model(x_t, t, cat, num) - eps)^2)."""
+    def _fold_padded(self) -> None:
+        for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters
+            gq = self.grads.get(self._pname[id(q)])
+            if gq is None:
+                continue
+            gp = self.PG(p)
+            gp.add_(gq[where].reshape(p.shape) if where is not None else gq.reshape(p.shape))
+
+    def forward_backward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor, eps: torch.Tensor,
+                         sync_group=False) -> torch.Tensor:
+        """Loss (device scalar, this rank's) and gradients (self.grads, by parameter name) of mean((model(x_t, t, cat, num) - eps)^2);
+        with sync_group (None = default group) the gradients are the data-parallel mean, reduced under the backward program."""
         pred = self.forward(x_t, t, cat, num)
         epsc = eps.contiguous()
         _lib.check(self.lib.tdx_mse_loss_grad(pred.data_ptr(), epsc.data_ptr(), self.dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
                                               self.red_ws.data_ptr(), _lib.stream_ptr()), "tdx_mse_loss_grad")
-        self.backward(self.dpred)
+        self.backward(self.dpred, sync_group=sync_group)
         return self.loss
 
     def named_gradients(self) -> Dict[str, torch.Tensor]:

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--breakdown", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="weight re-layout ops launched eagerly (needed under rocprofv3 --kernel-trace)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--per-op", type=int, default=0, help="with --breakdown: list the N slowest launches of each program on stderr")
     ap.add_argument("--overlap", action="store_true", help="N > 1: reduce gradient slices under the backward program instead of after it")
     ap.add_argument("--check-overlap", action="store_true", help="N > 1: assert that both reduction schedules give identical gradients")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
@@ -145,6 +146,9 @@ def main():
                 agg[fn][0] += 1
                 agg[fn][1] += ms
             out[tag + "_by_entry_point"] = {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            if a.per_op:
+                for name, fn, ms, fl in sorted(pg.profile(repeats=2), key=lambda r: -r[2])[: a.per_op]:
+                    print(f"{tag:9s} {name:44s} {fn:24s} {ms:8.4f} ms", file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -71,7 +71,7 @@ def test_adamw_matches_torch_optim():
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("n,c", [(1, 8), (300, 128), (33431, 384), (4096 * 13, 1024)])
+@pytest.mark.parametrize("n,c", [(1, 8), (100, 4), (300, 128), (5000, 64), (33431, 384), (1024, 2048), (4096 * 13, 1024), (1024 * 200, 128)])
 def test_colsum(dt, n, c):
     _, _lib = _eng()
     x = torch.randn(n, c + 8, generator=torch.Generator().manual_seed(n))

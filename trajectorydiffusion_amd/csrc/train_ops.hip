@@ -42,7 +42,42 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }
 
 // ---- column sums of a row-major (n, c) matrix: bias gradients, GroupNorm dgamma / dbeta ------------------------------------
-// stage 1: block (row slab, 64-column window) -> part[slab][c]; stage 2: fixed-order sum over slabs.
+// stage 1: block (row slab, column window) -> part[slab][c]; stage 2: fixed-order sum over slabs.
+// fp32 with c % 4 == 0 (every call of the training step): a lane owns 4 consecutive columns (16-byte loads, a wave reads
+// 1 KB of contiguous row data per load), four loads in flight per lane; lanes that share columns are combined with xor
+// shuffles, the four waves through LDS.  Anything else: the scalar kernel below.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ x, int ld, int n, int c, int lpr,
+                                                               float* __restrict__ part, int rows_per_slab) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rpw = 64 / lpr;                                  // rows one wave covers per load
+  const int col = blockIdx.y * 256 + (lane % lpr) * 4;       // (lpr = min(64, c / 4): windows only exist when lpr == 64)
+  const int r0 = blockIdx.x * rows_per_slab, r1 = min(n, r0 + rows_per_slab);
+  const int rstep = 4 * rpw;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (col < c) {
+    int r = r0 + wave * rpw + lane / lpr;
+    for (; r + (UNROLL - 1) * rstep < r1; r += UNROLL * rstep) {
+      f32x4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(r + u * rstep) * ld + col);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc += v[u];
+    }
+    for (; r < r1; r += rstep) acc += *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + col);
+  }
+  for (int o = 32; o >= lpr; o >>= 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < lpr && col < c) {
+    const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * c + col) = t;
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int ld, int n, int c, float* __restrict__ part, int slabs) {
   __shared__ float red[4][64];
@@ -56,12 +91,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   __syncthreads();
   if (sub == 0 && col < c) part[(size_t)blockIdx.x * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// block = 16 columns x 16 slab classes; class q adds slabs q, q + 16, ... in order, then the classes are added in order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int slabs, int c, float* __restrict__ out, int accumulate) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
+  __shared__ float red[16][17];
+  const int cj = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cj;
   float acc = 0.f;
-  for (int s = 0; s < slabs; ++s) acc += part[(size_t)s * c + col];
-  out[col] = accumulate ? out[col] + acc : acc;
+  if (col < c) {
+    int s = sub;
+    for (; s + 48 < slabs; s += 64) {
+      const float a = part[(size_t)s * c + col], b = part[(size_t)(s + 16) * c + col], d = part[(size_t)(s + 32) * c + col],
+                  e = part[(size_t)(s + 48) * c + col];
+      acc += a;
+      acc += b;
+      acc += d;
+      acc += e;
+    }
+    for (; s < slabs; s += 16) acc += part[(size_t)s * c + col];
+  }
+  red[sub][cj] = acc;
+  __syncthreads();
+  if (sub == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cj];
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 
 // ---- AdamW, one fused pass (torch.optim.AdamW single-tensor semantics, train.ipynb:131) --------------------------------
@@ -620,12 +675,27 @@ extern "C" int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_colsum: bad dtype %d", dtype);
   TDX_CHECK_ARG(c <= 4096, "tdx_colsum: c=%d exceeds the workspace (4096 columns)", c);
   hipStream_t st = (hipStream_t)stream;
-  int slabs = (n + 255) / 256;
+  int slabs;
+  if (dtype == TDX_F32 && c % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && (c <= 256 || c % 256 == 0)) {
+    const int lpr = c >= 256 ? 64 : c / 4;                   // lanes per row; c < 256 must be a power of two times 4
+    if ((lpr & (lpr - 1)) == 0) {
+      const int windows = (c + 255) / 256, rows_iter = 4 * (64 / lpr);
+      slabs = std::max(1, std::min(kRedBlocks, std::min(512 / windows, (n + 4 * rows_iter - 1) / (4 * rows_iter))));
+      const int rows_per_slab = ((n + slabs - 1) / slabs + rows_iter - 1) / rows_iter * rows_iter;
+      slabs = (n + rows_per_slab - 1) / rows_per_slab;
+      hipLaunchKernelGGL(colsum_partial_v4_kernel<4>, dim3((unsigned)slabs, (unsigned)windows), dim3(256), 0, st, (const float*)x, ld, n, c, lpr,
+                         ws, rows_per_slab);
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
+      TDX_CHECK_LAUNCH("colsum");
+      return TDX_OK;
+    }
+  }
+  slabs = (n + 255) / 256;
   if (slabs > kRedBlocks) slabs = kRedBlocks;
   const dim3 grid((unsigned)slabs, (unsigned)((c + 63) / 64));
   if (dtype == TDX_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, n, c, ws, slabs);
   else hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, ld, n, c, ws, slabs);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
   TDX_CHECK_LAUNCH("colsum");
   return TDX_OK;
 }

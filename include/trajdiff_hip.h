@@ -188,6 +188,23 @@ int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int3
 int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
                    float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
                    void* stream);
+/* One re-layout of a conv weight into the K order tdx_conv_gemm reads (fp32): for row < rows, channel < cin, tap < taps
+ *   dst[row * dst_ld + (channel / 32) * 32 * taps + tap * min(32, cin - 32 * (channel / 32)) + channel % 32]
+ *     = tap_map[tap] < 0 ? 0 : src[row * sr + channel * sc + tap_map[tap] * st]        (strides in elements).
+ * Forward weights (TrajUNetBlocks.py:77,86,89): rows = Cout, sr/sc/st = the parameter's strides, tap_map = {0,1,2};
+ * data-gradient weights: rows = Cin, sr and sc exchanged, tap_map = {2,1,0}. */
+typedef struct tdx_pack_desc {
+  const void* src;
+  void* dst;
+  int32_t rows, cin, taps, dst_ld;
+  int64_t sr, sc, st;
+  int32_t tap_map[3];
+  int32_t reserved;
+} tdx_pack_desc;
+/* Runs every entry of a DEVICE-resident table of n descriptors in one launch (the training step refreshes ~200 weight
+ * copies per step; one by one they are launch-bound).  No reference counterpart: torch keeps one layout. */
+int tdx_pack_weights(const tdx_pack_desc* table_dev, int32_t n, void* stream);
+
 /* Test hook, no reference counterpart: bit 0 keeps tdx_conv_wgrad off its large-tile kernel.  Returns the previous value. */
 int tdx_conv_wgrad_debug(int32_t force);
 

@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
                 ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cin", _i32), ("taps", _i32), ("dst_ld", _i32), ("sr", _i64), ("sc", _i64),
+                ("st", _i64), ("tap_map", _i32 * 3), ("reserved", _i32)]
+
+
 _SIGNATURES = {
     "tdx_last_error": (C.c_char_p, []),
     "tdx_version": (_i32, []),
@@ -56,6 +61,7 @@ _SIGNATURES = {
     "tdx_colsum": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "tdx_conv_wgrad_debug": (_i32, [_i32]),
+    "tdx_pack_weights": (_i32, [_vp, _i32, _vp]),
     "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
                                      _i32, _i32, _vp]),
     "tdx_interleave2": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -119,6 +119,27 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// ---- weight re-layout for the training step ------------------------------------------------------------------------------
+// Every step the parameters change, and with them the GEMM-layout copies the conv kernels read: the forward [Cout][K]
+// matrix, the tap-flipped transpose for the data gradient, the two phase matrices of a stride-2 data gradient
+// (engine.pack_conv_weight*).  All of them are "dst[row][(32-channel block, tap, channel)] = src[row*sr + ch*sc + tap_map[tap]*st]"
+// for some strides and tap map, so ONE launch walks a table of such copies (blockIdx.y = table entry).
+__global__ __launch_bounds__(256) void pack_weights_kernel(const tdx_pack_desc* __restrict__ table) {
+  const tdx_pack_desc d = table[blockIdx.y];
+  const int kk = d.cin * d.taps;
+  const long total = (long)d.rows * kk;
+  const float* __restrict__ src = reinterpret_cast<const float*>(d.src);
+  float* __restrict__ dst = reinterpret_cast<float*>(d.dst);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / kk), pos = (int)(i - (long)row * kk);
+    const int blk = pos / (32 * d.taps), within = pos - blk * 32 * d.taps;
+    const int cb = min(32, d.cin - blk * 32);   // (a last, narrower channel block keeps its taps adjacent too)
+    const int t = within / cb, c = within - t * cb;
+    const int tm = d.tap_map[t];
+    dst[(size_t)row * d.dst_ld + pos] = tm >= 0 ? src[(size_t)row * d.sr + (size_t)(blk * 32 + c) * d.sc + (size_t)tm * d.st] : 0.f;
+  }
+}
+
 // ---- AdamW, one fused pass (torch.optim.AdamW single-tensor semantics, train.ipynb:131) --------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float omb1, float beta2, float omb2, float eps,
@@ -893,4 +914,11 @@ extern "C" int tdx_conv_wgrad_debug(int32_t force) {
   const int old = g_wgrad_force;
   g_wgrad_force = force;
   return old;
+}
+
+extern "C" int tdx_pack_weights(const tdx_pack_desc* table_dev, int32_t n, void* stream) {
+  TDX_CHECK_ARG(table_dev && n > 0 && n <= 65535, "tdx_pack_weights: bad table (n=%d)", n);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev);
+  TDX_CHECK_LAUNCH("pack_weights_kernel");
+  return TDX_OK;
 }

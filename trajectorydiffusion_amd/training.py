@@ -8,10 +8,10 @@ data gradients run on the forward conv kernel (tdx_conv_gemm on dy with repacked
 tdx_conv_wgrad, GroupNorm+Swish on tdx_groupnorm_act_bwd, and so on (include/trajdiff_hip.h, "Training-step building
 blocks").  Activations are saved (no workspace reuse), statistics are recomputed.
 
-torch does plumbing only: device memory, the per-step re-packing of the weights (permute / cat / copy_ into fixed buffers),
+torch does plumbing only: device memory, padded stand-ins and bias sums (small copy_ ops into fixed buffers),
 embedding-row gathers, layout changes of the (B, 2, L) model input/output, and zeroing of gradient buffers.
 
-Not covered yet: dropout (TrajUNetBlocks.py:85; the step runs with it off, like the parity fixture), bf16, DDP all-reduce.
+Not covered: bf16 training (the reference trains in fp32).
 """
 from __future__ import annotations
 
@@ -50,7 +50,10 @@ class TrainStep:
         self.bw = engine.Program(device, torch.float32)
         self.bw.release = lambda t: None
         self._back: List[Callable[[], None]] = []
-        self._repack: List[Callable[[], None]] = []
+        self._repack: List[Callable[[], None]] = []        # torch plumbing refreshed every step: padded stand-ins, bias sums
+        self._repack_torch: List[Callable[[], None]] = []  # the weight layouts as torch statements (tests check tdx_pack_weights against them)
+        self._packs: List[Tuple["_Src", torch.Tensor, int, str]] = []
+        self._pack_tab: Optional[torch.Tensor] = None
         self._agrad: Dict[int, torch.Tensor] = {}   # id(activation) -> gradient buffer (zeroed every step)
         self._keep: List[torch.Tensor] = []
         self.params = dict(model.named_parameters())
@@ -123,6 +126,32 @@ class TrainStep:
         self._padded.append((q, p, None, where))
         return q
 
+    def _pack(self, s: "_Src", dst: torch.Tensor, col: int, mode: str) -> None:
+        """Register one tdx_pack_weights table entry: the layout engine.pack_conv_weight* would give the weight slice of s."""
+        self._packs.append((s, dst, col, mode))
+
+    def _pack_table(self) -> torch.Tensor:
+        rows = []
+        for s, dst, col, mode in self._packs:
+            v = s.wslice()
+            cout, cin, k = v.shape
+            s0, s1, s2 = v.stride()
+            if mode == "fwd":
+                d = (cout, cin, k, s0, s1, list(range(k)))
+            elif mode == "dgrad":          # engine.pack_conv_weight_dgrad: taps flipped, channel roles exchanged
+                d = (cin, cout, k, s1, s0, [k - 1 - t for t in range(k)])
+            elif mode == "dgrad_even":     # engine.pack_conv_weight_dgrad_stride2: dx[2m] = W_1^T dy[m]
+                d = (cin, cout, 1, s1, s0, [1])
+            else:                          # dx[2m + 1] = W_2^T dy[m] + W_0^T dy[m + 1]; taps read dy[m - 1], dy[m], dy[m + 1]
+                d = (cin, cout, 3, s1, s0, [-1, 2, 0])
+            nrow, nch, taps, sr, sc, tmap = d
+            if dst.shape[0] != nrow or col + nch * taps > dst.shape[1] or v.dtype != torch.float32:
+                raise TdxError("TrainStep: weight copy does not fit its buffer")
+            tm = (C.c_int32 * 3)(*(tmap + [0] * (3 - len(tmap))))
+            rows.append(_lib.PackDesc(v.data_ptr(), dst.data_ptr() + 4 * col, nrow, nch, taps, dst.shape[1], sr, sc, s2, tm, 0))
+        arr = (_lib.PackDesc * len(rows))(*rows)
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+
     # ---- ops --------------------------------------------------------------------------------------------------------------
     def conv(self, name: str, srcs: Sequence[_Src], cout: int, lout: int, out: torch.Tensor, out_off: int = 0,
              biases: Sequence[torch.Tensor] = (), res: Optional[torch.Tensor] = None, ebias: Optional[Tuple[torch.Tensor, int]] = None,
@@ -130,7 +159,11 @@ class TrainStep:
         B, fw, lib = self.B, self.fw, self.lib
         ktot = sum(s.taps * s.cin for s in srcs)
         wp = self._new(cout, ktot)
-        self._repack.append(lambda: wp.copy_(torch.cat([engine.pack_conv_weight(s.wslice(), torch.float32) for s in srcs], dim=1)))
+        self._repack_torch.append(lambda: wp.copy_(torch.cat([engine.pack_conv_weight(s.wslice(), torch.float32) for s in srcs], dim=1)))
+        koff = 0
+        for s in srcs:
+            self._pack(s, wp, koff, "fwd")
+            koff += s.taps * s.cin
         bsum = None
         if biases:
             bsum = self._new(cout)
@@ -150,11 +183,14 @@ class TrainStep:
                     a, b = engine.pack_conv_weight_dgrad_stride2(s.wslice(), torch.float32)
                     we.copy_(a)
                     wo.copy_(b)
-                self._repack.append(rp)
+                self._repack_torch.append(rp)
+                self._pack(s, we, 0, "dgrad_even")
+                self._pack(s, wo, 0, "dgrad_odd")
                 dgrad_w.append((we, wo))
             else:
                 wd = self._new(s.cin, s.taps * cout)
-                self._repack.append(lambda s=s, wd=wd: wd.copy_(engine.pack_conv_weight_dgrad(s.wslice(), torch.float32)))
+                self._repack_torch.append(lambda s=s, wd=wd: wd.copy_(engine.pack_conv_weight_dgrad(s.wslice(), torch.float32)))
+                self._pack(s, wd, 0, "dgrad")
                 dgrad_w.append(wd)
 
         def backward():
@@ -399,15 +435,16 @@ class TrainStep:
 
     # ---- one step -----------------------------------------------------------------------------------------------------------
     def _refresh_packed_weights(self) -> None:
-        """Re-derive the GEMM-layout copies (forward, flipped/transposed for the data gradients, padded stand-ins) from the
-        parameters' current values.  ~200 small layout ops: launch-bound when issued one by one, so they are captured once
-        into a HIP graph and replayed; the capture is redone if a parameter's storage has moved."""
+        """Re-derive the GEMM-layout copies from the parameters' current values: padded stand-ins and bias sums are a few
+        dozen small torch ops (captured once into a HIP graph and replayed), then ONE tdx_pack_weights launch writes every
+        forward / data-gradient weight layout from a device-resident table.  Both are rebuilt if a parameter's storage moves."""
+        key = tuple(p.data_ptr() for p in self.params.values())
+        if self._repack_key != key:
+            self._repack_graph, self._pack_tab, self._repack_key = None, self._pack_table(), key
         if not self._graph_repack:
             for f in self._repack:
                 f()
-            return
-        key = tuple(p.data_ptr() for p in self.params.values())
-        if self._repack_graph is None or self._repack_key != key:
+        elif self._repack_graph is None:
             for f in self._repack:                      # eager once: warms the allocator and makes the copies valid now
                 f()
             torch.cuda.synchronize()
@@ -415,9 +452,10 @@ class TrainStep:
             with torch.cuda.graph(g):
                 for f in self._repack:
                     f()
-            self._repack_graph, self._repack_key = g, key
+            self._repack_graph = g
         else:
             self._repack_graph.replay()
+        _lib.check(self.lib.tdx_pack_weights(self._pack_tab.data_ptr(), len(self._packs), _lib.stream_ptr()), "tdx_pack_weights")
 
     def forward(self, x_t: torch.Tensor, t: torch.Tensor, cat: torch.Tensor, num: torch.Tensor) -> torch.Tensor:
         """eps_hat (B, 2, L) of the training-mode forward pass; activations stay saved for backward()."""

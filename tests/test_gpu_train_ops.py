@@ -86,7 +86,7 @@ def test_colsum(dt, n, c):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("case", ["k3", "k3_s2", "k3_up", "k1", "concat_half", "ragged", "big_k3", "big_up", "big_k1", "big_concat", "big_short",
-                                  "big_one_row"])
+                                  "big_one_row", "big_s2", "big_s2_odd"])
 def test_conv_weight_gradient(dt, case):
     """dW of nn.Conv1d from autograd, for every source map the forward conv supports."""
     engine, _lib = _eng()
@@ -112,6 +112,10 @@ def test_conv_weight_gradient(dt, case):
         Ci, Co, ci_off, cin_total = 128, 128, 128, 384
     elif case == "big_short":       # several trajectory boundaries inside every 32-row chunk
         B, L, Ci, Co = 70, 13, 128, 128
+    elif case == "big_s2":          # stride 2, even length: the even / odd row window
+        stride, Ci, Co = 2, 128, 256
+    elif case == "big_s2_odd":      # odd length (25 -> 13): the last output row has no odd source row
+        stride, B, L, Ci, Co = 2, 41, 25, 256, 128
     elif case == "big_one_row":     # the embedding MLP's linears: lout = 1, every row is first and last of its trajectory
         B, L, Ci, Co, k = 100, 1, 128, 256, 1
     cin_total = cin_total or Ci

@@ -236,11 +236,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 // the three taps read at row offsets 0/1/2 (96 flop/B), with per-row flags masking the rows that belong to the neighbouring
 // trajectory.  Each of the 8 waves holds 64 co x 32 ci x TAPS accumulators (96 VGPRs); the next chunk's global loads are
 // in flight (registers) while the current chunk is multiplied.  Rows are VIRTUAL rows (b, u) of the nearest-upsampled
-// source, mapped to stored rows by the loader, so upsampled sources take this path too.
-template <int TAPS>
+// source, mapped to stored rows by the loader, so upsampled sources take this path too; stride-2 convs use a window of
+// even / odd source rows per output row (S2, below).
+template <int TAPS, bool S2>
 __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int RC = 32, PAD = TAPS == 3 ? 1 : 0, WR = RC + 2 * PAD, LD = 144;  // 144 mod 64 = 16: the 4 k rows hit disjoint banks
+  static_assert(!S2 || TAPS == 3, "the stride-2 form exists for 3-tap convs only");
+  // Stride 2 (S2): output row n = (b, l) reads source rows 2l - 1, 2l, 2l + 1.  The window holds, per output row, the EVEN row
+  // 2l (rows 0..31) and the ODD row 2l + 1 of rows n0 - 1 .. n0 + 31 (rows 32..64): tap 1 reads even[n], tap 2 odd[n], tap 0
+  // odd[n - 1] (masked on a trajectory's first row) -- indexed by output row, so trajectory boundaries need no special case.
+  constexpr int RC = 32, PAD = TAPS == 3 ? 1 : 0, WR = S2 ? 2 * RC + 1 : RC + 2 * PAD, LD = 144;  // 144 mod 64 = 16: the 4 k rows hit disjoint banks
   constexpr int XV = (WR * 32 + 511) / 512;                                     // float4 loads of the X window per thread
   __shared__ __attribute__((aligned(16))) float dys[RC * LD];
   __shared__ __attribute__((aligned(16))) float xs[WR * LD];
@@ -272,19 +277,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) 
 #pragma unroll
     for (int q = 0; q < XV; ++q) {  // X window: WR virtual rows x 32 float4
       const int e = tid + q * 512, row = e >> 5, c4 = (e & 31) * 4;
-      const int m = r0 - PAD + row;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < WR && m >= 0 && m < p.N) {
-        const int b = m / p.lvirt, u = m - b * p.lvirt;
-        const int srow = p.up_scale > 0.f ? min((int)floorf((float)u * p.up_scale), p.lin - 1) : u;
-        v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * p.lin + srow) * p.x_ld + c4);
+      if constexpr (S2) {
+        const int odd = row >= RC ? 1 : 0;
+        const int n = odd ? r0 - 1 + (row - RC) : r0 + row;
+        if (row < WR && n >= 0 && n < p.N) {
+          const int b = n / p.lout, u = 2 * (n - b * p.lout) + odd;
+          if (u < p.lin) v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * p.lin + u) * p.x_ld + c4);
+        }
+      } else {
+        const int m = r0 - PAD + row;
+        if (row < WR && m >= 0 && m < p.N) {
+          const int b = m / p.lvirt, u = m - b * p.lvirt;
+          const int srow = p.up_scale > 0.f ? min((int)floorf((float)u * p.up_scale), p.lin - 1) : u;
+          v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * p.lin + srow) * p.x_ld + c4);
+        }
       }
       xreg[q] = v;
     }
     if (tid < WR) {
-      const int m = r0 - PAD + tid;
-      const int u = m >= 0 ? m % p.lvirt : 0;
-      freg = (u == 0 ? 1 : 0) | (u == p.lvirt - 1 ? 2 : 0);
+      const int m = S2 ? r0 + tid : r0 - PAD + tid;   // S2: flags are per OUTPUT row (only the first RC entries are read)
+      const int len = S2 ? p.lout : p.lvirt;
+      const int u = m >= 0 ? m % len : 0;
+      freg = (u == 0 ? 1 : 0) | (u == len - 1 ? 2 : 0);
     }
   };
   auto stash = [&]() {
@@ -314,12 +329,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) 
       for (int i = 0; i < 4; ++i) a[i] = dys[kr * LD + cob + i * 16 + l16];
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        const int wr = kr + t;  // window row of the source row that output row kr reads through tap t
+        const int wr = S2 ? (t == 1 ? kr : RC + kr + (t == 2 ? 1 : 0)) : kr + t;  // window row that output row kr reads through tap t
         float bv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) bv[j] = xs[wr * LD + cib + j * 16 + l16];
         if (TAPS == 3 && t != 1) {
-          const bool dead = (flags[wr] & (t == 0 ? 2 : 1)) != 0;  // tap 0 never reads a trajectory's last row, tap 2 never its first
+          // tap 0 never reads a trajectory's last row, tap 2 never its first; S2: tap 0 of a first row is the only dead read
+          const bool dead = S2 ? (t == 0 && (flags[kr] & 1) != 0) : (flags[wr] & (t == 0 ? 2 : 1)) != 0;
           bv[0] = dead ? 0.f : bv[0];
           bv[1] = dead ? 0.f : bv[1];
         }
@@ -752,7 +768,8 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   const int N = B * lout;
   const int64_t per_split = (int64_t)cout * s.cin * s.taps;
   hipStream_t st = (hipStream_t)stream;
-  const bool big = !(g_wgrad_force & 1) && dtype == TDX_F32 && s.stride == 1 && cout % 128 == 0 && s.cin % 128 == 0 && dy_ld % 4 == 0 &&
+  const bool s2 = s.stride == 2;
+  const bool big = !(g_wgrad_force & 1) && dtype == TDX_F32 && (!s2 || (s.taps == 3 && s.lvirt == s.lin)) && cout % 128 == 0 && s.cin % 128 == 0 && dy_ld % 4 == 0 &&
                    dy_off % 4 == 0 && s.src_ld % 4 == 0 && s.ch_off % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)s.src & 15) == 0;
   int splits;
   if (big) {  // one 512-thread workgroup per CU: aim at two full rounds of the 256 CUs
@@ -769,8 +786,9 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   splits = (N + a.rows_per_split - 1) / a.rows_per_split;
   if (big) {
     const dim3 grid((unsigned)(cout / 128), (unsigned)(s.cin / 128), (unsigned)splits);
-    if (s.taps == 3) hipLaunchKernelGGL(conv_wgrad_big_kernel<3>, grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_big_kernel<1>, grid, dim3(512), 0, st, a);
+    if (s2) hipLaunchKernelGGL((conv_wgrad_big_kernel<3, true>), grid, dim3(512), 0, st, a);
+    else if (s.taps == 3) hipLaunchKernelGGL((conv_wgrad_big_kernel<3, false>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_big_kernel<1, false>), grid, dim3(512), 0, st, a);
   } else {
     const dim3 grid((unsigned)((cout + 63) / 64), (unsigned)(((s.cin + 63) / 64) * s.taps), (unsigned)splits);
     if (dtype == TDX_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, a);

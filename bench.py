@@ -151,7 +151,7 @@ def main():
                          "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms, 3),
                          "all_kernels_ms_per_step": round(step_ms, 3)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the other ranks must not idle at the final barrier for it
             out["cpu_baseline"] = cpu_baseline(L, a.T)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -188,6 +188,23 @@ int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int3
 int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
                    float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
                    void* stream);
+/* ---- Evaluation metrics over sampled trajectories (eval_trajunet.ipynb cell 12; next-row widening) ----------
+ * Workspace for the calls below: tdx_metric_workspace_bytes(number of histogram bins) bytes of device memory. */
+int64_t tdx_metric_workspace_bytes(int32_t n_bins_total);
+/* getPointDistribution / getStartDistribution / getEndDistribution (cell 12): traj (B, 2, L) fp32; the points
+ * l_first <= l < l_first + l_count of every trajectory are counted on an n_grids x n_grids grid whose boundaries are
+ * torch.linspace(min, max, n_grids) of the points' own lon / lat range, bin = torch.searchsorted(grid, value);
+ * out[lon_bin * n_grids + lat_bin] = normalize ? (count + 1) / sum(count) : count. */
+int tdx_point_distribution(const float* traj, int32_t B, int32_t L, int32_t l_first, int32_t l_count, int32_t n_grids,
+                           int32_t normalize, float* out, void* ws, int64_t ws_bytes, void* stream);
+/* getLengthDistribution (cell 12): path length sum_l |p[l+1] - p[l]| of every trajectory, binned with
+ * torch.searchsorted(torch.linspace(lo, hi, n_bins), length); out = (count + 0.1) / sum(count).  lengths (B) is optional.
+ * err[0] is set to 1 (never cleared) when a length exceeds hi: the reference raises IndexError there. */
+int tdx_length_distribution(const float* traj, int32_t B, int32_t L, float lo, float hi, int32_t n_bins, float* out,
+                            float* lengths, int32_t* err, void* ws, int64_t ws_bytes, void* stream);
+/* JSD (cell 12): 0.5 * (kl_div(log P, M) + kl_div(log Q, M)), M = (P + Q) / 2, 'batchmean' over `batch` = P.shape[0]. */
+int tdx_jsd(const float* P, const float* Q, int64_t n, int32_t batch, float* out, void* stream);
+
 /* One re-layout of a conv weight into the K order tdx_conv_gemm reads (fp32): for row < rows, channel < cin, tap < taps
  *   dst[row * dst_ld + (channel / 32) * 32 * taps + tap * min(32, cin - 32 * (channel / 32)) + channel % 32]
  *     = tap_map[tap] < 0 ? 0 : src[row * sr + channel * sc + tap_map[tap] * st]        (strides in elements).

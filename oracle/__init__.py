@@ -12,3 +12,4 @@ itself in the build container (``tests/golden/make_golden.py``).
 from .trajunet_oracle import trajunet_forward, embed_forward, resnet_block, attn_block, nearest_index_map  # noqa: F401
 from .diffusion_oracle import DiffusionOracle  # noqa: F401
 from .dataset_oracle import didi_item, gaussian_cell_boundaries  # noqa: F401
+from . import metrics_oracle  # noqa: F401  (evaluation metrics, parity unpinned)

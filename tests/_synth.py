@@ -89,3 +89,18 @@ def sample_view(t: torch.Tensor, n: int = 2048) -> np.ndarray:
     flat = t.detach().reshape(-1).to(torch.float32)
     stride = max(1, flat.numel() // n)
     return flat[::stride][:n].numpy().copy()
+
+
+def synth_metric_trajectories(B: int, L: int, seed: int):
+    """Two (B, 2, L) fp32 sets ("real" and "generated") of random walks in z-scored lon/lat units for the evaluation metrics;
+    step sizes spread the path lengths over the reference's 0..10 histogram range without leaving it."""
+    import numpy as np
+    import torch
+    sets = []
+    for k in range(2):
+        rng = np.random.Generator(np.random.PCG64(1000 * seed + k))
+        start = rng.normal(0.0, 1.0 + 0.2 * k, size=(B, 2, 1))
+        scale = rng.uniform(0.2, 8.0, size=(B, 1, 1)) / (1.6 * (L - 1))
+        steps = rng.normal(0.0, 1.0, size=(B, 2, L - 1)) * scale
+        sets.append(torch.from_numpy(np.concatenate([start, start + np.cumsum(steps, axis=2)], axis=2).astype(np.float32)))
+    return sets[0], sets[1]

@@ -98,3 +98,27 @@ def test_dataset_items(golden_dir):
         np.testing.assert_array_equal(c.numpy(), g["cat"][i])
         np.testing.assert_array_equal(n.numpy(), g["num"][i])
         np.testing.assert_array_equal(tm.numpy(), g["times"][i])
+
+
+def test_metrics_oracle_self_consistency():
+    """oracle/metrics_oracle.py is PARITY UNPINNED (no reference fixtures exist for eval_trajunet.ipynb cell 12): checked here are
+    the properties the reference's code implies, and the restated linspace against torch's (CPU kernel: <= 1 ulp apart)."""
+    import numpy as np
+    import torch
+    from _synth import synth_metric_trajectories
+    from oracle import metrics_oracle as mo
+    for a, b, n in ((-1.7, 2.9, 16), (0.0, 10.0, 64), (3.0, 3.5, 7)):
+        g, t = mo.linspace_f32(a, b, n), torch.linspace(a, b, n).numpy()
+        assert g[0] == np.float32(a) and g[-1] == np.float32(b) and np.all(np.diff(g) > 0)
+        assert np.abs(g - t).max() <= 2 * np.spacing(np.float32(max(abs(a), abs(b))))
+    t0, t1 = synth_metric_trajectories(64, 200, 1)
+    raw = mo.point_distribution(t0, 16, False)
+    assert raw.sum() == 64 * 200 and raw[0].sum() >= 1 and raw[-1].sum() >= 1      # min lands in row 0, max in row 15
+    p, q = mo.point_distribution(t0), mo.point_distribution(t1)
+    assert abs(p.sum() - (64 * 200 + 256) / (64 * 200)) < 1e-5
+    assert mo.jsd(p, p) == 0.0 and mo.jsd(p, q) > 0 and abs(mo.jsd(p, q) - mo.jsd(q, p)) < 1e-9
+    assert mo.start_distribution(t0).shape == (16, 16) and mo.length_distribution(t0).shape == (64,)
+    one = torch.zeros(1, 2, 3)
+    one[0, 0] = torch.tensor([0.0, 3.0, 3.0])
+    one[0, 1] = torch.tensor([0.0, 4.0, 4.0])
+    assert mo.path_lengths(one)[0] == 5.0

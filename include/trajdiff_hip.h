@@ -222,8 +222,6 @@ typedef struct tdx_pack_desc {
  * copies per step; one by one they are launch-bound).  No reference counterpart: torch keeps one layout. */
 int tdx_pack_weights(const tdx_pack_desc* table_dev, int32_t n, void* stream);
 
-/* Test hook, no reference counterpart: bit 0 keeps tdx_conv_wgrad off its large-tile kernel.  Returns the previous value. */
-int tdx_conv_wgrad_debug(int32_t force);
 
 /* Backward of tdx_groupnorm_act (nn.GroupNorm + Swish, TrajUNetBlocks.py:75-76,83-84): from the forward INPUT x and the
  * gradient dy of the activated output, dx (+)= gradient of x; dgamma_rows / dbeta_rows (B, C) fp32 receive each

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrajdiff_hip.so")
+LIB_PATH = os.environ.get("TDX_LIB_PATH") or os.path.join(_HERE, "libtrajdiff_hip.so")   # (override: A/B runs of two builds)
 
 TDX_F32, TDX_BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_SWISH = 0, 1, 2

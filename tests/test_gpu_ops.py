@@ -133,6 +133,49 @@ def test_conv_concat_plus_shortcut_segments(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("seed", range(16))
+def test_conv_seeded_random_shapes(dt, seed):
+    """Random (seeded) shapes across every routing decision of tdx_conv_gemm: small / large row counts (register-staged, one-tile
+    and persistent kernels), ragged last tiles, channel counts that are and are not whole 128-byte blocks, taps, stride 2,
+    nearest upsampling, and every combination of the optional epilogue operands.  The output is pre-filled with NaN."""
+    rng = np.random.default_rng(1000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    mode = ["plain", "plain", "s2", "up"][seed % 4]
+    taps = 3 if mode != "plain" or rng.random() < 0.7 else 1
+    Ci = int(rng.choice([32, 64, 96, 128, 192, 256, 512]))
+    Co = int(rng.choice([8, 64, 96, 128, 256, 384, 512]))
+    L = int(rng.integers(1, 60)) if rng.random() < 0.7 else int(rng.integers(150, 211))
+    big = seed % 2 == 1                                         # odd seeds: enough rows for the LDS-DMA kernels' >= 128 tiles
+    rows_target = int(rng.integers(33000, 60000)) if big else int(rng.integers(1, 3000))
+    B = max(1, min(rows_target // max(L, 1), 4000))
+    if B * L * Ci > 12_000_000:
+        B = max(1, 12_000_000 // (L * Ci))
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, taps, generator=g) / (taps * Ci) ** 0.5
+    b = torch.randn(Co, generator=g) if rng.random() < 0.8 else None
+    stride, up = (2, None) if mode == "s2" else (1, None)
+    if mode == "up":
+        up = 2 * L - int(rng.integers(0, 2))
+    xin = F.interpolate(q(x, dt), size=up, mode="nearest") if up else q(x, dt)
+    pre = F.conv1d(xin, q(w, dt), b, stride=stride, padding=taps // 2)
+    lo = pre.shape[2]
+    res = torch.randn(B, Co, lo, generator=g) if rng.random() < 0.4 else None
+    eb = torch.randn(B, Co + 8, generator=g) if rng.random() < 0.4 else None
+    tb = torch.randn(Co + 8, generator=g) if rng.random() < 0.4 else None
+    act = int(rng.choice([0, 0, 1, 2]))
+    if eb is not None:
+        pre = pre + eb[:, 8:, None]
+    if tb is not None:
+        pre = pre + tb[None, 8:, None]
+    ref = (pre, F.leaky_relu(pre, 0.1), swish(pre))[act]
+    if res is not None:
+        ref = ref + q(res, dt)
+    got = run_conv(dt, x, w, b, stride=stride, upmap_to=up, act=act, res=res, ebias=eb, tbias=tb)
+    assert got.shape == ref.shape and bool(torch.isfinite(got).all()), (mode, B, L, Ci, Co, taps)
+    assert rel(got, ref) < TOL[dt], (mode, B, L, Ci, Co, taps, act, res is not None, eb is not None, tb is not None)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("case", ["s1_c128", "s1_c256", "s2", "up", "k1_res", "tail_rows", "stream_win", "stream_s2", "stream_up", "stream_c128"])
 def test_conv_large_tiles_dma_kernel(dt, case):
     """Shapes big enough for the LDS-DMA kernels (window and gather variants, persistent and one-tile-per-workgroup forms,

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--low-latency", action="store_true", help="small-batch serving mode: split-K convs (TrajUNet.set_low_latency)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +81,7 @@ def main():
     from trajectorydiffusion_amd import DiffusionManager, TrajUNet
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)  # same random-init weights on every rank
-    model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype)
+    model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype).set_low_latency(a.low_latency)
     dm = DiffusionManager(1e-4, 0.05, a.T, device=str(dev))
     dm.seed = 2024
     B, L = a.batch, a.L
@@ -94,7 +95,7 @@ def main():
         else:
             x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, x0)
+            dist.all_gather_into_tensor(gathered, x0.contiguous())
         return x0
 
     def fence():

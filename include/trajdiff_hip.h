@@ -91,6 +91,12 @@ typedef struct {
   int32_t gn_ld, gn_off, gn_act, gn_cpg;
   float gn_eps;
   int32_t reserved2;
+  /* Optional split-K workspace (device, fp32): when given, a problem too small to fill the chip (few output tiles, long K:
+   * the single-trajectory / small-batch serving case) is cut along K into up to ws_bytes / (4 * B * lout * cout) slices that
+   * run as concurrent workgroups; a second kernel adds the slices in order and applies the epilogue.  Results are
+   * reproducible, but the fp32 summation order differs from the unsplit kernels (and so may the last bit).  NULL = never. */
+  void* ws;
+  int64_t ws_bytes;
 } tdx_conv_desc;
 int tdx_conv_gemm(const tdx_conv_desc* host_desc, void* stream);
 /* 1 if tdx_conv_gemm can run this descriptor WITH its fused GroupNorm, 0 if the caller must run

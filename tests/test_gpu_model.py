@@ -243,3 +243,23 @@ def test_c3_ddim_shard_size_properties(model):
         model._programs.clear()
         torch.cuda.empty_cache()
         model.set_compute_dtype(torch.float32)
+
+
+def test_low_latency_mode_matches_golden_and_default_path(model, golden_dir):
+    """TrajUNet.set_low_latency(): split-K convs at small batch; fp32 forward still within 1e-4 of the reference's output."""
+    g = np.load(os.path.join(golden_dir, "forward.npz"))
+    B, L = 4, 200
+    x, t, cat, num = synth_inputs(B, L, T_MODEL, seed=1)
+    args = (x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+    model.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        base = model(*args).clone()
+        try:
+            model.set_low_latency(True)
+            fast = model(*args).clone()
+            again = model(*args).clone()
+        finally:
+            model.set_low_latency(False)
+    assert torch.equal(fast, again) and not torch.equal(fast, base)       # reproducible, and the split path really ran
+    assert rel(fast.cpu(), base.cpu()) < 1e-5
+    assert rel(fast.cpu(), g["B4_L200/eps"]) < FP32_TOL

@@ -34,11 +34,13 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def run_conv(dt, x, w, b, stride=1, upmap_to=None, act=0, res=None, ebias=None, tbias=None):
+def run_conv(dt, x, w, b, stride=1, upmap_to=None, act=0, res=None, ebias=None, tbias=None, split_k_floats=0):
     engine, _lib = _eng()
     B, Ci, L = x.shape
     Co = w.shape[0]
     pg = engine.Program(torch.device("cuda"), dt)
+    if split_k_floats:
+        pg.split_k_ws = torch.full((split_k_floats,), float("nan"), device="cuda")
     src = rows(x, dt)
     if upmap_to is not None:
         lo = upmap_to
@@ -130,6 +132,44 @@ def test_conv_concat_plus_shortcut_segments(dt):
     pg.conv(segs, wp, b.cuda(), out, Co, B, L, Co)
     pg.run()
     assert rel(unrows(out), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", ["k3", "k3_ragged", "s2", "up", "k1_epilogue", "tiny_ws", "one_row"])
+def test_conv_split_k_small_batches(dt, case):
+    """tdx_conv_desc.ws: few output tiles and a long K loop are cut into K slices (concurrent workgroups) and summed in order by
+    a second kernel.  Same result as the unsplit kernel up to fp32 summation order, and identical on repetition."""
+    g = torch.Generator().manual_seed(len(case))
+    B, L, Ci, Co, taps, stride, up = 1, 13, 1024, 1024, 3, 1, None
+    ws = 4 << 20
+    if case == "k3_ragged":
+        B, L, Ci, Co = 3, 7, 480, 200
+    elif case == "s2":
+        B, L, Ci, Co, stride = 2, 25, 512, 256, 2
+    elif case == "up":
+        B, L, Ci, Co, up = 2, 13, 512, 384, 25
+    elif case == "k1_epilogue":
+        B, L, Ci, Co, taps = 4, 13, 2048, 512, 1
+    elif case == "tiny_ws":
+        ws = B * L * Co * 3            # room for three slices only
+    elif case == "one_row":
+        B, L, Ci, Co, taps = 1, 1, 1280, 256, 1     # the embedding MLP at batch 1
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, taps, generator=g) / (taps * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xin = F.interpolate(q(x, dt), size=up, mode="nearest") if up else q(x, dt)
+    pre = F.conv1d(xin, q(w, dt), b, stride=stride, padding=taps // 2)
+    kw = {}
+    if case == "k1_epilogue":
+        res, eb, tb = torch.randn(pre.shape, generator=g), torch.randn(B, Co + 8, generator=g), torch.randn(Co + 8, generator=g)
+        pre = swish(pre + eb[:, 8:, None] + tb[None, 8:, None]) + q(res, dt)
+        kw = dict(act=2, res=res, ebias=eb, tbias=tb)
+    plain = run_conv(dt, x, w, b, stride=stride, upmap_to=up, **kw)
+    split = run_conv(dt, x, w, b, stride=stride, upmap_to=up, split_k_floats=ws, **kw)
+    assert rel(plain, pre) < TOL[dt] and rel(split, pre) < TOL[dt]
+    assert rel(split, plain) < (2e-6 if dt == torch.float32 else 1e-2)
+    assert not torch.equal(split, plain) or case == "one_row" or dt == torch.bfloat16      # the split path really ran (fp32: other rounding)
+    assert torch.equal(split, run_conv(dt, x, w, b, stride=stride, upmap_to=up, split_k_floats=ws, **kw))
 
 
 @pytest.mark.parametrize("dt", DT)

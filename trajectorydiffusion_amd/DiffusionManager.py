@@ -114,7 +114,7 @@ class DiffusionManager:
         from .Models.TrajUNet import TrajUNet
         if isinstance(model, TrajUNet):
             from .sampler import GraphSampler
-            key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, max_t, "ddpm")
+            key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, max_t, "ddpm", getattr(model, "low_latency", False))
             smp = self._samplers.get(key)
             if smp is None or not smp.valid():
                 smp = GraphSampler(self, model, x_T.shape[0], x_T.shape[2], x_T.device, max_t)
@@ -140,7 +140,7 @@ class DiffusionManager:
         from .sampler import GraphSampler
         if not isinstance(model, TrajUNet):
             raise TdxError("ddimBackward: only this package's TrajUNet is supported")
-        key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, n_steps, "ddim")
+        key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, n_steps, "ddim", getattr(model, "low_latency", False))
         smp = self._samplers.get(key)
         if smp is None or not smp.valid():
             smp = GraphSampler(self, model, x_T.shape[0], x_T.shape[2], x_T.device, self.T, ddim_steps=n_steps)

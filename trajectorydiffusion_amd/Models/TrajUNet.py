@@ -21,6 +21,8 @@ class UNetProgram:
     def __init__(self, model: "TrajUNet", B: int, L: int, dtype: torch.dtype, device: torch.device, split_embed: bool):
         self.B, self.L, self.dtype, self.split_embed = B, L, dtype, split_embed
         pg = engine.Program(device, dtype)
+        if model.low_latency:
+            pg.split_k_ws = torch.empty(8 << 20, dtype=torch.float32, device=device)   # 32 MiB of split-K slices
         self.pg = pg
         f32 = torch.float32
         self.x = pg.alloc((B, 2, L), f32)          # x_t in, updated in place by the sampler
@@ -190,6 +192,14 @@ class TrajUNet(_HipBlock):
         self.embed_cols = off
         self._packed: Dict[torch.dtype, Tuple[int, Dict[str, torch.Tensor]]] = {}
         self._programs: Dict[Tuple, UNetProgram] = {}
+        self.low_latency = False
+
+    def set_low_latency(self, on: bool = True) -> "TrajUNet":
+        """Small-batch serving mode (no reference counterpart): convs with too few output tiles to fill the 256 CUs are cut
+        along K into concurrent slices (tdx_conv_desc.ws).  Off by default because the fp32 summation order, and with it the
+        last bit of the result, then depends on the batch size: batch shards are no longer bit-identical to the unsharded run."""
+        self.low_latency = bool(on)
+        return self
 
     # ---- structure helpers ---------------------------------------------------------------------
     def executed_resblocks(self):
@@ -233,7 +243,7 @@ class TrajUNet(_HipBlock):
     def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> UNetProgram:
         dtype = self.compute_dtype if dtype is None else dtype
         self.packed_weights(dtype)  # refresh (drops stale programs) before the cache lookup
-        key = (B, L, dtype, device, split_embed)
+        key = (B, L, dtype, device, split_embed, self.low_latency)
         prog = self._programs.get(key)
         if prog is None:
             prog = UNetProgram(self, B, L, dtype, device, split_embed)

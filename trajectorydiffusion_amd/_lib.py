@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("tbias", _vp), ("ebias_ld", _i32), ("ebias_off", _i32), ("res", _vp), ("res_ld", _i32), ("act", _i32),
                 ("out", _vp), ("out_ld", _i32), ("out_off", _i32), ("B", _i32), ("lout", _i32), ("cout", _i32),
                 ("reserved", _i32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_ld", _i32), ("gn_off", _i32),
-                ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32)]
+                ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32), ("ws", _vp), ("ws_bytes", _i64)]
 
 
 class PackDesc(C.Structure):

@@ -52,6 +52,9 @@ struct ConvArgs {
   int32_t gn_ld, gn_off, gn_act, gn_cpg, gn_L;
   float gn_eps;
   int32_t debug;  // ablation bits for scripts/conv_bench.py: 1 = no loads after the first stage, 2 = no MFMA, 4 = no stores
+  // split-K (register-staged kernel only): blockIdx.y = slice z computes K-steps [z * steps_per_split, ...) into partial[z][n][co]
+  float* partial;
+  int32_t ksplit, steps_per_split;
 };
 
 int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
@@ -92,6 +95,55 @@ struct Mma<float> {
 
 // Epilogue shared by both kernels: bias (+ per-sample / per-step embed bias) -> act -> (+ residual) -> store.
 // Lane (fr, fq) of a 16x16 sub-tile (mi, ni) holds 4 consecutive channels co..co+3 of output row n.
+// One output row n, four consecutive channels co..co+3, accumulated value v: bias (+ per-step / per-trajectory embed rows) ->
+// act -> (+ residual) -> store.  Shared by the register-staged kernel's epilogue and the split-K reduction.
+template <typename T>
+__device__ __forceinline__ void finish4(const ConvArgs& p, int n, int b, int co, float (&v)[4]) {
+  // same association as the LDS-DMA epilogues: acc + (bias + time-step row) + per-trajectory row
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] += t[j];
+  }
+  if (p.tbias) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.tbias + p.ebias_off + co);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] += t[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] += bs[j];
+  if (p.ebias) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)b * p.ebias_ld + p.ebias_off + co);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += t[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = tdx_act(v[j], p.act);
+  if constexpr (sizeof(T) == 4) {
+    if (p.res) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.res_ld + co) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += t[j];
+    }
+    *reinterpret_cast<f32x4*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+    if (p.res) {
+      const u32x2 t = *reinterpret_cast<const u32x2*>(p.res + ((size_t)n * p.res_ld + co) * 2);
+      v[0] += __uint_as_float(t[0] << 16);
+      v[1] += __uint_as_float(t[0] & 0xffff0000u);
+      v[2] += __uint_as_float(t[1] << 16);
+      v[3] += __uint_as_float(t[1] & 0xffff0000u);
+    }
+    u32x2 o;
+    o[0] = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
+           ((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
+    o[1] = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
+           ((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+    *reinterpret_cast<u32x2*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * 2) = o;
+  }
+}
+
 template <typename T, int MI, int NI>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4 (&acc)[MI][NI], int n_base, int co_base, int fr, int fq) {
 #pragma unroll
@@ -106,51 +158,35 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4 (&acc)[MI][NI]
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j];
-      // same association as the LDS-DMA epilogues: acc + (bias + time-step row) + per-trajectory row
-      float bs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] += t[j];
-      }
-      if (p.tbias) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.tbias + p.ebias_off + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] += t[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += bs[j];
-      if (p.ebias) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)b * p.ebias_ld + p.ebias_off + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += t[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = tdx_act(v[j], p.act);
-      if constexpr (sizeof(T) == 4) {
-        if (p.res) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.res_ld + co) * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += t[j];
-        }
-        *reinterpret_cast<f32x4*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * 4) = (f32x4){v[0], v[1], v[2], v[3]};
-      } else {
-        if (p.res) {
-          const u32x2 t = *reinterpret_cast<const u32x2*>(p.res + ((size_t)n * p.res_ld + co) * 2);
-          v[0] += __uint_as_float(t[0] << 16);
-          v[1] += __uint_as_float(t[0] & 0xffff0000u);
-          v[2] += __uint_as_float(t[1] << 16);
-          v[3] += __uint_as_float(t[1] & 0xffff0000u);
-        }
-        u32x2 o;
-        o[0] = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
-               ((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
-        o[1] = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
-               ((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
-        *reinterpret_cast<u32x2*>(p.out + ((size_t)n * p.out_ld + p.out_off + co) * 2) = o;
-      }
+      finish4<T>(p, n, b, co, v);
     }
   }
+}
+// Split-K: slice z leaves its raw fp32 sums in partial[z][n][co]; splitk_finish_kernel adds the slices in order.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_partial(const ConvArgs& p, f32x4 (&acc)[MI][NI], int n_base, int co_base, int fr, int fq, int z) {
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n_base + ni * 16 + fr;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int co = co_base + mi * 16 + fq * 4;
+      if (co >= p.cout) continue;
+      *reinterpret_cast<f32x4*>(p.partial + ((size_t)z * p.N + n) * p.cout + co) = acc[mi][ni];
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvArgs p) {
+  const int c4 = p.cout >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)p.N * c4) return;
+  const int n = (int)(i / c4), co = (int)(i - (long)n * c4) * 4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(p.partial + (size_t)n * p.cout + co);
+  for (int z = 1; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.N + n) * p.cout + co);
+  float v[4] = {s[0], s[1], s[2], s[3]};
+  finish4<T>(p, n, n / p.lout, co, v);
 }
 
 
@@ -453,6 +489,22 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
   };
   set_rows();
 
+  auto advance = [&]() {
+    if (++it_tap >= p.seg[it_seg].taps) {
+      it_tap = 0;
+      it_ci += BK;
+      if (it_ci >= p.seg[it_seg].cin) {
+        it_ci = 0;
+        ++it_seg;
+        if (it_seg < p.nseg) set_rows();
+      }
+    }
+  };
+  // split-K: this workgroup owns K-steps [s_begin, s_end)
+  const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.steps_per_split : 0;
+  const int s_end = p.ksplit > 1 ? min(p.nsteps, s_begin + p.steps_per_split) : p.nsteps;
+  for (int s = 0; s < s_begin; ++s) advance();
+
   u32x4 ra[RA], rx[RB];
   auto load_step = [&]() {
     const SegDev& s = p.seg[it_seg];
@@ -473,15 +525,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
         rx[i] = *reinterpret_cast<const u32x4*>(g);
       }
     });
-    if (++it_tap >= s.taps) {
-      it_tap = 0;
-      it_ci += BK;
-      if (it_ci >= s.cin) {
-        it_ci = 0;
-        ++it_seg;
-        if (it_seg < p.nseg) set_rows();
-      }
-    }
+    advance();
   };
   auto store_step = [&](int buf) {
     char* a = smem + buf * (A_BYTES + B_BYTES);
@@ -525,14 +569,16 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const ConvArgs p) {
   load_step();
   store_step(0);
   __syncthreads();
-  for (int s = 0; s < p.nsteps; ++s) {
-    const bool more = s + 1 < p.nsteps;
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool more = s + 1 < s_end;
+    const int buf = (s - s_begin) & 1;
     if (more) load_step();
-    compute(s & 1);
-    if (more) store_step((s + 1) & 1);
+    compute(buf);
+    if (more) store_step(buf ^ 1);
     __syncthreads();
   }
-  epilogue<T, MI, NI>(p, acc, n0 + wr * (TR / 2), co0 + wc * (TC / 2), fr, fq);
+  if (p.ksplit > 1) epilogue_partial<MI, NI>(p, acc, n0 + wr * (TR / 2), co0 + wc * (TC / 2), fr, fq, (int)blockIdx.y);
+  else epilogue<T, MI, NI>(p, acc, n0 + wr * (TR / 2), co0 + wc * (TC / 2), fr, fq);
 }
 
 template <typename T, int TR, int TC>
@@ -547,7 +593,12 @@ int launch(const ConvArgs& a, hipStream_t st) {
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
+  grid.y = a.ksplit > 1 ? (unsigned)a.ksplit : 1u;
   hipLaunchKernelGGL((conv_gemm_kernel<T, TR, TC>), grid, dim3(kThreads), lds, st, a);
+  if (a.ksplit > 1) {
+    const long quads = (long)a.N * (a.cout >> 2);
+    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a);
+  }
   TDX_CHECK_LAUNCH("conv_gemm_kernel");
   return TDX_OK;
 }
@@ -1557,6 +1608,9 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   a.cout = d->cout;
   a.B = d->B;
   a.debug = g_debug;
+  a.partial = nullptr;
+  a.ksplit = 1;
+  a.steps_per_split = 0;
   a.tile_rows = kDmaRows;
   a.gn_L = d->lout;
   a.gn_cpg = vec;
@@ -1665,6 +1719,18 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   if (rc != TDX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (ch.kind != 0) return d->dtype == TDX_F32 ? run_dma<float>(a, ch, st) : run_dma<__bf16>(a, ch, st);
+  // Few tiles and a long K loop (small batches): cut K into slices that run as concurrent workgroups, if the caller gave room.
+  const int64_t tiles128 = (int64_t)((a.N + 127) / 128) * ((a.cout + 127) / 128);
+  if (d->ws && !(g_force & 64) && a.cout % 4 == 0 && tiles128 < 128 && a.nsteps >= 4 && ((uintptr_t)d->ws & 15) == 0) {
+    const int64_t slice_bytes = (int64_t)a.N * a.cout * 4;
+    int want = (int)std::min<int64_t>(a.nsteps / 2, (512 + tiles128 - 1) / tiles128);   // ~2 workgroups per CU, >= 2 K-steps each
+    want = (int)std::min<int64_t>(want, d->ws_bytes / slice_bytes);
+    if (want >= 2) {
+      a.steps_per_split = (a.nsteps + want - 1) / want;
+      a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+      a.partial = (float*)d->ws;
+    }
+  }
   if (d->dtype == TDX_F32) return launch<float, 128, 128>(a, st);
   return launch<__bf16, 128, 128>(a, st);
 }
@@ -1672,7 +1738,7 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
 // Test hooks (not part of the reference-facing surface).
 // force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable,
 //             8 = never use the 128-row (two workgroups per CU) tiles, 16 = no tail split, 32 = one tile per workgroup
-//             (no persistent kernel), 128 = 128-channel tiles for every Cout;
+//             (no persistent kernel), 64 = never split K, 128 = 128-channel tiles for every Cout;
 //             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation).
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   g_force = bits & 0xff;

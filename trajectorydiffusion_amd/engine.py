@@ -109,6 +109,9 @@ class Program:
         # GroupNorm pass (full-chip HBM stream) beats a longer, un-overlapped epilogue on every TrajUNet shape
         # (profiles/r1_gn_fusion_ablation.txt), so programs use it only on request.
         self.fuse_gn = FUSE_GN_DEFAULT
+        # fp32 workspace that lets tdx_conv_gemm cut K into concurrent slices when a conv has too few tiles to fill the chip
+        # (small batches); shared by every conv of the program (they run one after the other on one stream).  None = never.
+        self.split_k_ws: Optional[torch.Tensor] = None
 
     # ---- workspace -------------------------------------------------------------------------
     def alloc(self, shape: Sequence[int], dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -167,6 +170,8 @@ class Program:
                     d.out, d.out_ld, d.out_off = out.data_ptr(), cout, 0
                     out_ld, out_off = cout, 0
             self.keep.extend([gn.gamma, gn.beta, gn.out])
+        if self.split_k_ws is not None and not fused:
+            d.ws, d.ws_bytes = self.split_k_ws.data_ptr(), self.split_k_ws.numel() * self.split_k_ws.element_size()
         self.keep.extend([d, w, bias, out, res, ebias, tbias])
         self._add(name, self.lib.tdx_conv_gemm, C.byref(d))
         self.flops[len(self.ops) - 1] = 2.0 * B * lout * cout * ktot

@@ -19,7 +19,7 @@ class GraphSampler:
         self.dm, self.model, self.B, self.L, self.device = dm, model, B, L, device
         self.lib = _lib.lib()
         self.prog = model.program(B, L, device, split_embed=True)
-        self._prog_key = (B, L, model.compute_dtype, device, True)
+        self._prog_key = (B, L, model.compute_dtype, device, True, model.low_latency)
         self.ddim = ddim_steps is not None
         ab = dm.alpha_bars.view(-1).cpu()
         if self.ddim:

@@ -40,6 +40,9 @@ class _Src:
 
 
 class TrainStep:
+    """The training step of one (B, L) batch shape: forward and backward programs built once, then
+    forward_backward() / optimizer_step() per batch (or forward() + backward() behind torch.autograd, see train_forward)."""
+
     def __init__(self, model, B: int, L: int, device: torch.device, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: int = 0, graph_repack: bool = True):
         self.m, self.B, self.L, self.dev = model, B, L, device

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Evaluation metrics (eval_trajunet.ipynb cell 12) on B sampled trajectories: HIP-event time per metric, achieved HBM rate
-against the algorithmic bytes (point histogram: every coordinate read twice; lengths: once), the oracle on the host beside it.
+against the algorithmic bytes (point histogram: every coordinate read twice; lengths: once).  (No CPU leg: the oracle is for
+tests/, smoke() and bench.py's cpu_baseline only.)
 
     python scripts/metrics_bench.py [--batch 65536] [--L 200]
 """
@@ -8,7 +9,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import torch
 
@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--L", type=int, default=200)
     a = ap.parse_args()
     from _synth import synth_metric_trajectories
-    from oracle import metrics_oracle as mo
     from trajectorydiffusion_amd import metrics as m
     t0, _ = synth_metric_trajectories(a.batch, a.L, 11)
     d = t0.cuda()
@@ -45,16 +44,9 @@ def main():
         if passes:
             rows[name]["algorithmic_GBps"] = round(passes * nbytes / best / 1e6, 1)
             rows[name]["frac_of_8TBps"] = round(passes * nbytes / best / 1e6 / 8000, 4)
-    sub = t0[:2048]
-    tc = time.perf_counter()
-    mo.point_distribution(sub)
-    mo.length_distribution(sub)
-    cpu = time.perf_counter() - tc
     gpu_ms = rows["getPointDistribution"]["ms"] + rows["getLengthDistribution"]["ms"]
     print(json.dumps({"workload": f"evaluation metrics, B={a.batch}, L={a.L}, fp32", "per_metric": rows,
-                      "trajectories_per_s_point_plus_length": round(a.batch / (gpu_ms * 1e-3)),
-                      "cpu_oracle": {"trajectories_per_s": round(2048 / cpu), "sample": "vectorised numpy/torch restatement on 2048 trajectories",
-                                     "note": "the reference itself loops over points in Python (~1e4 points/s)"}}))
+                      "trajectories_per_s_point_plus_length": round(a.batch / (gpu_ms * 1e-3))}))
 
 
 if __name__ == "__main__":

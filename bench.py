@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--batch B] [--T 500]
 
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`, spawned before
+any GPU call); launched by torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+
 One "step" = one full T-step diffusionBackward over a batch of B synthetic trajectories per GPU
 (config C2: B=4096, L=200, T=500).  N>1 (launched by torch.distributed.run, one rank per GPU) shards
 trajectories across ranks with no data-path collective; the final all_gather of x_0 is inside the
@@ -51,7 +55,20 @@ def cpu_baseline(L, T_total, seconds_budget=20.0):
             "sample": f"oracle (torch CPU fp32) B={B} L={L}: {steps} of {T_total} DDPM steps timed in {dt:.1f}s, scaled to {T_total} steps"}
 
 
-def main():
+def newest_traffic_file(profiles_dir=None):
+    """profiles/r<NN>_pmc_traffic.json of the highest round present (PMC passes are separate rocprofv3 runs, so the figure
+    is stored per round by scripts/pmc_traffic.py; the bench line says which file it read)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return best[1] if best else None
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -61,25 +78,19 @@ def main():
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--L", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 (reference arithmetic) run of the same config")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--low-latency", action="store_true", help="small-batch serving mode: split-K convs (TrajUNet.set_low_latency)")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
 
+def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
+    """Time `steps` full sampling runs in one compute dtype; returns (elapsed seconds (max over ranks), model, x0)."""
     from _synth import synth_inputs
     from trajectorydiffusion_amd import DiffusionManager, TrajUNet
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     torch.manual_seed(0)  # same random-init weights on every rank
     model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype).set_low_latency(a.low_latency)
     dm = DiffusionManager(1e-4, 0.05, a.T, device=str(dev))
@@ -104,11 +115,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    x0 = None
+    for _ in range(warmup):
         x0 = one_step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         x0 = one_step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -117,25 +129,69 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    dm._samplers.clear()   # the sampler owns GBs of workspace and a captured graph
+    return elapsed, model
 
-    if rank == 0:
-        value = world * B * a.steps / elapsed
-        n_denoise = a.ddim_steps if a.sampler == "ddim" else a.T
-        # roofline of the dominant kernel (conv_gemm): per-launch HIP-event times of one denoise step
-        prog = model.program(B, L, dev, split_embed=True)
-        prof = prog.pg.profile(repeats=3)
-        gemm = [(n, ms, fl) for n, fn, ms, fl in prof if fn == "tdx_conv_gemm"]
-        gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
-        step_ms = sum(ms for _, _, ms, _ in prof)
-        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), stored per round
-        traffic = None
+
+def conv_roofline(model, a, dtype_name, dev):
+    """Roofline of the dominant kernel (conv GEMM): per-launch HIP-event times of one denoise step, on the launch stream."""
+    B, L = a.batch, a.L
+    prog = model.program(B, L, dev, split_embed=True)
+    prof = prog.pg.profile(repeats=3)
+    gemm = [(n, ms, fl) for n, fn, ms, fl in prof if fn == "tdx_conv_gemm"]
+    gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
+    step_ms = sum(ms for _, _, ms, _ in prof)
+    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+    # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), stored per round
+    traffic, src = None, newest_traffic_file()
+    if src is not None:
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pm["workload"] == f"B={B}, L={L}, {a.dtype}":
+            pm = json.load(open(src))
+            if pm["workload"] == f"B={B}, L={L}, {dtype_name}":
                 traffic = round(pm["conv_gemm_bytes_per_launch_avg"])
         except (OSError, KeyError, ValueError):
             pass
+    es = 2 if dtype_name == "bf16" else 4
+    others = {}
+    for n, fn, ms, fl in prof:
+        if fn != "tdx_conv_gemm":
+            others[fn] = round(others.get(fn, 0.0) + ms, 4)
+    return {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call = main grid + optional small-tile tail grid; all %d calls of one denoise step)" % len(gemm),
+            "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4),
+            "traffic": traffic, "traffic_source": (os.path.relpath(src, ROOT) + " (rocprofv3 --pmc, bytes per launch, avg over the calls of one step)") if traffic is not None else None,
+            "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * es * B / len(gemm)), "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
+            "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms, 3),
+            "other_kernels_ms_per_step": others, "all_kernels_ms_per_step": round(step_ms, 3)}
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    # `python bench.py --gpus N`: this process becomes the launcher of N ranks (a child torch.distributed.run), before any
+    # GPU call is made here; the ranks re-enter main() with RANK/WORLD_SIZE set and rank 0 prints the JSON line.
+    from trajectorydiffusion_amd.distributed import spawn_ranks_if_needed
+    rc = spawn_ranks_if_needed(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), a.gpus)
+    if rc is not None:
+        sys.exit(rc)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; the line reports the RCCL world size", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()
+
+    B, L = a.batch, a.L
+    elapsed, model = run_leg(a, a.dtype, a.steps, a.warmup, rank, world, dev, dist)
+    n_denoise = a.ddim_steps if a.sampler == "ddim" else a.T
+    out = None
+    if rank == 0:
+        value = world * B * a.steps / elapsed
         out = {
             "metric": "trajectories/sec, TrajUNet 500-step DDPM sampling L=200" if a.sampler == "ddpm" and a.T == 500 else f"trajectories/sec, TrajUNet {a.sampler} sampling ({n_denoise} denoise steps) L={L}", "value": round(value, 3), "unit": "trajectories/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
@@ -145,13 +201,22 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "diffusion_steps": a.T, "parallelism": f"batch-shard x{world}"},
             "ms_per_denoise_step": round(1e3 * elapsed / a.steps / n_denoise, 4),
             "model_tflops": round(value * n_denoise * FLOP_PER_TRAJ_STEP / 1e12 / world, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call = main grid + optional small-tile tail grid; all %d calls of one denoise step)" % len(gemm),
-                         "achieved": round(achieved, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.dtype], 4),
-                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, bytes per launch, avg of 38)",
-                         "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * 2 * B / 38) if a.dtype == "bf16" else None, "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
-                         "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms, 3),
-                         "all_kernels_ms_per_step": round(step_ms, 3)},
+            "roofline": conv_roofline(model, a, a.dtype, dev),
         }
+    del model
+    torch.cuda.empty_cache()
+    # The reference's own arithmetic (fp32: exact f32 MFMA, the 1e-4 parity path) on the same config, in the same run:
+    # one warm-up + one timed sampling run (BASELINE.json config 2 names "fp32 + bf16").
+    if a.dtype == "bf16" and not a.no_fp32_leg:
+        el32, m32 = run_leg(a, "fp32", 1, 1, rank, world, dev, dist)
+        if rank == 0:
+            out["fp32"] = {"value": round(world * B / el32, 3), "unit": "trajectories/s", "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * el32, 3),
+                           "ms_per_denoise_step": round(1e3 * el32 / n_denoise, 4),
+                           "model_tflops": round(B / el32 * n_denoise * FLOP_PER_TRAJ_STEP / 1e12, 2),
+                           "roofline": conv_roofline(m32, a, "fp32", dev)}
+        del m32
+        torch.cuda.empty_cache()
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the other ranks must not idle at the final barrier for it
             out["cpu_baseline"] = cpu_baseline(L, a.T)
         print(json.dumps(out), flush=True)

@@ -140,9 +140,10 @@ int tdx_embed_gather(const int64_t* time, const int64_t* cat, const float* num, 
 /* DDPM posterior step, DiffusionManager.py:46-55, fused into one coalesced pass:
  *   x = (x - c_eps * eps) / sqrt_alpha + sigma * z     coef = {beta/sqrt(1-abar), sqrt(alpha), sqrt(beta)} (device, 3 floats)
  * z = injected noise tensor, or NULL to draw N(0,1) in-kernel (Philox4x32-10 + Box-Muller keyed by
- * (seed ^ dyn_seed, step, first_elem + element index) so results do not depend on how the batch is sharded;
- * step_ctr is NULL or a device int32[4] = {step, dyn_seed_lo, dyn_seed_hi, reserved}, read at run time so
- * a captured graph can be replayed with a new step / seed).  sigma == 0 (t == 0) adds no noise.  In place on x. */
+ * (seed ^ dyn_seed, stream, first_elem + element index) so results do not depend on how the batch is sharded;
+ * step_ctr is NULL or a device int32[4] = {step, dyn_seed_lo, dyn_seed_hi, stream}, read at run time so
+ * a captured graph can be replayed with a new step / seed; stream = the diffusion step t in every sampling path, so the
+ * eager per-step call and the graph-replayed loop draw the same noise).  sigma == 0 (t == 0) adds no noise.  In place on x. */
 int tdx_ddpm_update(float* x, const float* eps, const float* z, const float* coef, int64_t n,
                     uint64_t seed, const int32_t* step_ctr, int64_t first_elem, void* stream);
 
@@ -152,7 +153,8 @@ int tdx_ddim_update(float* x, const float* eps, const float* coef, int64_t n, vo
 
 /* Sampling-loop bookkeeping kept on the device so one captured hipGraph can be replayed T times:
  * reads step = *step_ctr, copies coef_table[step, 0:ncoef] -> coef_cur and
- * tbias_table[step, 0:ntb] -> tbias_cur, fills t_vec[0:B] = step_to_t[step], then *step_ctr = step + 1.
+ * tbias_table[step, 0:ntb] -> tbias_cur, fills t_vec[0:B] = step_to_t[step], sets step_ctr[3] = step_to_t[step] (the Philox
+ * stream id tdx_ddpm_update reads; = step without a table), then *step_ctr = step + 1.
  * Replaces the host-side indexing in DiffusionManager.py:46-48,70-72. */
 int tdx_step_prepare(int32_t* step_ctr, const float* coef_table, int32_t ncoef, float* coef_cur,
                      const float* tbias_table, int32_t ntb, float* tbias_cur, const int32_t* step_to_t,
@@ -173,7 +175,8 @@ int tdx_didi_items(const float* lon_lat_raw, const float* minutes, const float* 
 int tdx_didi_denorm(const float* lon_lat, const float* stats, float* out_deg, int32_t B, int32_t L, void* stream);
 
 /* ---- Training-step building blocks (train.ipynb:198-209).  fp32 arithmetic; every reduction has a
- * fixed order (two stages through a caller-provided workspace, no atomics).  The step itself is not assembled yet. ---- */
+ * fixed order (two stages through a caller-provided workspace, no atomics).  trajectorydiffusion_amd/training.py assembles the step
+ * (forward program, tape-recorded backward program, fused AdamW, data-parallel gradient mean) from these. ---- */
 
 /* Floats a workspace `ws` must hold for tdx_mse_loss_grad and tdx_colsum. */
 int64_t tdx_train_workspace_floats(void);

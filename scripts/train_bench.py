@@ -2,7 +2,8 @@
 """Config C4: one TrajUNet training step (q_sample -> forward -> MSE -> backward -> AdamW), fp32, B=1024, L=200.
 
     python scripts/train_bench.py [--batch 1024] [--steps 5] [--warmup 2] [--breakdown] [--no-graph]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/train_bench.py   # data parallel
+    python scripts/train_bench.py --gpus 8 --overlap                # data parallel: starts the 8 ranks itself (child torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/train_bench.py   # the same, launched by hand
 
 With N ranks every rank steps its own B trajectories (weak scaling) and the gradients are averaged over RCCL
 (TrainStep.sync_gradients) between backward and the optimizer; the time is the max over ranks.
@@ -30,6 +31,7 @@ FLOP_PER_TRAJ_FWD = 2 * 1_015_085_824
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without RANK in the environment: spawn N ranks (one per GPU, RCCL) as a child process")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--L", type=int, default=200)
     ap.add_argument("--T", type=int, default=500)
@@ -43,6 +45,10 @@ def main():
     ap.add_argument("--check-overlap", action="store_true", help="N > 1: assert that both reduction schedules give identical gradients")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
     a = ap.parse_args()
+    from trajectorydiffusion_amd.distributed import spawn_ranks_if_needed
+    rc = spawn_ranks_if_needed(os.path.abspath(__file__), sys.argv[1:], a.gpus)   # before any GPU call
+    if rc is not None:
+        sys.exit(rc)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

@@ -118,12 +118,17 @@ dist.barrier(); dist.destroy_process_group(); print("rank", rank, "ok")
 '''
 
 
+def _free_port():
+    from trajectorydiffusion_amd.distributed import free_port
+    return free_port()
+
+
 def test_two_process_shard_and_gather_equals_unsharded(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29571", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+                        "--master-port", str(_free_port()), str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
 
@@ -165,7 +170,7 @@ def test_two_process_gradient_mean_equals_full_batch_gradient(tmp_path):
     script.write_text(_DP_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29573", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+                        "--master-port", str(_free_port()), str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
 
@@ -181,3 +186,112 @@ def test_persistent_conv_kernels_have_no_spills_in_their_k_loops():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_spills.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_rank_launcher_builds_the_torchrun_child_command(monkeypatch):
+    """`python bench.py --gpus N` must itself start N ranks: a CHILD `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`, spawned before any GPU call."""
+    from trajectorydiffusion_amd import distributed as D
+    cmd = D.rank_launch_command("/x/bench.py", ["--gpus", "8", "--steps", "3"], 8, port=12345, python="py")
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "12345",
+                   "/x/bench.py", "--gpus", "8", "--steps", "3"]
+    calls = []
+
+    class _R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return _R()
+    monkeypatch.setattr(D.subprocess, "run", fake_run)
+    monkeypatch.delenv("RANK", raising=False)
+    assert D.spawn_ranks_if_needed("/x/bench.py", ["--gpus", "1"], 1) is None and not calls         # N == 1: run in this process
+    assert D.spawn_ranks_if_needed("/x/bench.py", ["--gpus", "4"], 4) == 7
+    (cmd, env), = calls
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4"] and cmd[-3:] == ["/x/bench.py", "--gpus", "4"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("RANK", "0")                                                                    # already a rank: never spawn again
+    assert D.spawn_ranks_if_needed("/x/bench.py", ["--gpus", "4"], 4) is None and len(calls) == 1
+
+
+@pytest.mark.parametrize("script", ["bench.py", os.path.join("scripts", "train_bench.py")])
+def test_bench_gpus_flag_spawns_ranks_before_any_gpu_call(script, monkeypatch):
+    """The driver runs `python bench.py --gpus N`; with N > 1 the script must hand over to the launcher (exit code relayed)
+    without touching the GPU in the launching process."""
+    import importlib.util
+    import torch
+    from trajectorydiffusion_amd import distributed as D
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, script))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = []
+
+    class _R:
+        returncode = 0
+
+    monkeypatch.setattr(D.subprocess, "run", lambda cmd, env=None, **kw: (seen.append(cmd), _R())[1])
+    monkeypatch.delenv("RANK", raising=False)
+
+    def boom(*a, **k):
+        raise AssertionError("GPU touched before the ranks were spawned")
+    monkeypatch.setattr(torch.cuda, "set_device", boom)
+    monkeypatch.setattr(sys, "argv", [script, "--gpus", "8", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        mod.main()
+    assert e.value.code == 0
+    (cmd,), n = seen, 8
+    assert f"--nproc-per-node={n}" in cmd and cmd[-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith(script)
+
+
+def test_bench_reports_the_world_size_and_newest_traffic_file(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in ("r1_pmc_traffic.json", "r2_pmc_traffic.json", "r10_pmc_traffic.json", "r3_pmc_traffic_old.json"):
+        (tmp_path / name).write_text("{}")
+    assert os.path.basename(mod.newest_traffic_file(str(tmp_path))) == "r10_pmc_traffic.json"
+    assert mod.newest_traffic_file(str(tmp_path / "missing")) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"n_gpus": world' in src and "world = dist.get_world_size()" in src       # the line reports the RCCL world, not the flag
+
+
+def test_gradient_overlap_schedule_invariants():
+    """The data-parallel training step starts the RCCL all-reduce of a gradient slice right after the backward launch that
+    completes it (TrainStep.backward).  The schedule is pure host logic: slices cover the buffer exactly once, are issued in
+    non-decreasing readiness order, every gradient has a writer, and a slice is never ready before its last writer."""
+    from trajectorydiffusion_amd.distributed import bucket_plan, scan_gradient_writers
+    rng = np.random.default_rng(0)
+    base = 0x7F0000000000
+    names, spans_addr, off = [], [], 0
+    for i in range(23):                                   # 23 gradients, 64-float aligned like TrainStep's arena
+        n = int(rng.integers(1, 5000))
+        spans_addr.append((base + 4 * off, base + 4 * (off + n), f"p{i}"))
+        names.append(f"p{i}")
+        off += (n + 63) // 64 * 64
+    used = off
+    # a backward program of 40 launches: gradient i is written by launch 39 - i (reverse layer order) and, for some, by an
+    # earlier launch too (accumulating writers: the LAST one counts); p22 only through a fold after the program
+    launches = [[] for _ in range(40)]
+    for i, (lo, hi, n) in enumerate(spans_addr[:-1]):
+        launches[39 - i].append(lo)
+        if i % 3 == 0:
+            launches[max(0, 39 - i - 5)].append(lo + 4 * 7)        # pointer into the middle of the span
+    for a in launches:
+        a += [3, 17, True, base - 64, base + 4 * used + 128, None, 2.5]   # non-pointer arguments and addresses outside the buffer
+    ready = scan_gradient_writers(spans_addr, launches, base, base + 4 * used, folded=["p22"])
+    assert ready["p22"] == 40 and all(ready[f"p{i}"] == 39 - i for i in range(22))
+    with pytest.raises(ValueError):
+        scan_gradient_writers(spans_addr, launches, base, base + 4 * used)           # p22 has no writer
+    spans = [((lo - base) // 4, (hi - base) // 4, ready[n]) for lo, hi, n in spans_addr]
+    for bucket_bytes in (256, 3000, 1 << 20):
+        plan = bucket_plan(spans, used, bucket_bytes)
+        cover = sorted((lo, hi) for lo, hi, _ in plan)
+        assert cover[0][0] == 0 and cover[-1][1] == used and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        assert all(hi - lo <= max(64, bucket_bytes // 4) for lo, hi, _ in plan)
+        assert [r for _, _, r in plan] == sorted(r for _, _, r in plan)
+        for lo, hi, r in plan:
+            need = max((rd for a, b, rd in spans if a < hi and b > lo), default=0)
+            assert r == need
+    assert bucket_plan(spans, 0, 1024) == []

@@ -57,7 +57,7 @@ class DidiTrajectoryDataset(data.Dataset):
                 break
             file_path = self.file_paths[self.part_idx]
             print(f'Loading {file_path}')
-            for (_, _, lon_lat, times) in torch.load(file_path):
+            for (_, _, lon_lat, times) in torch.load(file_path, weights_only=True):   # list of (id, id, Tensor, Tensor): nothing in the file is executed
                 if lon_lat.shape[0] >= self.traj_length:
                     self.dataset_part.append((lon_lat[:self.traj_length].to(torch.float32),  # fp32 BEFORE normalising (:83)
                                               ((times[:self.traj_length] - self.time_shift) / 60).to(torch.float32)))

@@ -87,16 +87,27 @@ class DiffusionManager:
         if noise is not None and t > 0:
             z = noise.to(device=out.device, dtype=torch.float32).contiguous()
         seed = self._draw_seed() if z is None else 0
-        # stream id for Philox = t, passed through a tiny device int so the same kernel serves graph replay
-        ctr = torch.full((1,), t, dtype=torch.int32, device=out.device)
+        # {step, seed_lo, seed_hi, Philox stream id = t}: the same words the graph-replayed loop keeps on the device, so both
+        # paths draw the same noise for the same seed
+        ctr = torch.tensor(self.seed_words(seed, t), dtype=torch.int32).to(out.device)
         _lib.check(_lib.lib().tdx_ddpm_update(out.data_ptr(), eps.data_ptr(), _lib.ptr(z), self._coef_dev[t].data_ptr(), out.numel(),
-                                              seed, ctr.data_ptr(), 0, _lib.stream_ptr()), "tdx_ddpm_update")
+                                              0, ctr.data_ptr(), 0, _lib.stream_ptr()), "tdx_ddpm_update")
         return out
 
+    @staticmethod
+    def seed_words(seed: int, t: int = 0):
+        """Device words {step, seed_lo, seed_hi, stream} of tdx_ddpm_update's step_ctr for a 62-bit seed."""
+        return [int(t), seed & 0x7fffffff, (seed >> 31) & 0x7fffffff, int(t)]
+
     def _draw_seed(self) -> int:
+        """62-bit Philox seed: dm.seed when set (rejected beyond 62 bits: the device words are two 31-bit halves), else
+        drawn from torch's CPU generator (follows torch.manual_seed)."""
         if self.seed is not None:
-            return int(self.seed) & ((1 << 64) - 1)
-        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())  # follows torch.manual_seed
+            seed = int(self.seed)
+            if not 0 <= seed < (1 << 62):
+                raise ValueError(f"DiffusionManager.seed={seed} outside [0, 2**62)")
+            return seed
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     # ---- the sampling loop (reference :57-79) ------------------------------------------------------------
     @torch.no_grad()

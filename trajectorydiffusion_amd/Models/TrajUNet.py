@@ -54,9 +54,11 @@ class UNetProgram:
         self._emit_unet(model, packed)
 
     def _emit_unet(self, m: "TrajUNet", packed: Dict[str, torch.Tensor]) -> None:
-        """Dataflow: every conv GEMM's epilogue also applies the GroupNorm(+Swish) of its consumer, so a ResnetBlock is
-        two launches and the only stand-alone GroupNorm kernels left are the one after the stem and the skip halves of
-        the decoder concats."""
+        """Dataflow: every conv GEMM is recorded together with the GroupNorm(+Swish) of its consumer (engine.Program.conv,
+        `gn=`).  By default that GroupNorm runs as its own tdx_groupnorm_act launch right behind the conv (measured faster
+        on MI355X, profiles/r1_gn_fusion_ablation.txt); with Program.fuse_gn it is applied in the conv's epilogue where the
+        library can.  Stand-alone GroupNorms with no conv producer: the one after the stem and the skip halves of the
+        decoder concats."""
         pg, B, L = self.pg, self.B, self.L
         cs, NE, R = m.channel_schedule, m.embed_cols, m.res_blocks
         eb, tb = self.ebias, self.tbias
@@ -190,7 +192,8 @@ class TrajUNet(_HipBlock):
             self.embed_offsets[key] = off
             off += blk.out_c
         self.embed_cols = off
-        self._packed: Dict[torch.dtype, Tuple[int, Dict[str, torch.Tensor]]] = {}
+        self._packed: Dict[torch.dtype, Tuple] = {}   # dtype -> (version sum, parameter addresses, norm digest, tensors)
+        self.weights_epoch = 0                          # bumped by every (re)pack: samplers re-derive their time-step tables
         self._programs: Dict[Tuple, UNetProgram] = {}
         self.low_latency = False
 
@@ -212,15 +215,30 @@ class TrajUNet(_HipBlock):
             for j in range(self.res_blocks - 1):
                 yield f"up_blocks.{i}.{j}.", self.up_blocks[i][j]
 
-    def _weights_version(self) -> int:   # (not "_version": nn.Module keeps its state_dict format version under that name)
-        return sum(p._version for p in self.parameters())
+    def _fingerprint(self) -> Tuple[int, Tuple[int, ...]]:
+        """(sum of the parameters' autograd versions, their storage addresses).  In-place updates through the parameter
+        (optimizers, load_state_dict, copy_ under no_grad) bump a version; p.data = t / load_state_dict(assign=True) / .to()
+        change an address.  Writes through `.data` (param.data.copy_(...), the reference's Utils.EMA.getModel, Utils.py:107) change
+        NEITHER: the sampler detects them with _data_digest(); for a bare eval forward() call invalidate() after such a write."""
+        ps = list(self.parameters())
+        return sum(p._version for p in ps), tuple(p.data_ptr() for p in ps)
 
-    def packed_weights(self, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
-        """GEMM-layout weights in the compute dtype, rebuilt whenever a parameter changes."""
-        ver = self._weights_version()
-        hit = self._packed.get(dtype)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+    def _data_digest(self) -> Optional[torch.Tensor]:
+        """Per-parameter L2 norms on the device (236 floats): compared against the norms the cached GEMM-layout copies were
+        built from, this catches weight updates that no version counter sees.  One pass over 190 MB, no host sync of its own."""
+        ps = [p.detach() for p in self.parameters()]
+        if not ps or not all(p.is_cuda for p in ps):
+            return None
+        return torch.stack(torch._foreach_norm(ps))
+
+    def invalidate(self) -> "TrajUNet":
+        """Force the cached GEMM-layout weight copies to be refreshed before the next forward / sampling call.  Needed only
+        after writing weights through `.data` before a bare eval-mode forward(); everything else is detected."""
+        for dt, hit in list(self._packed.items()):
+            self._packed[dt] = (-1,) + tuple(hit[1:])
+        return self
+
+    def _build_packed(self, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
         out: Dict[str, torch.Tensor] = {}
         with torch.no_grad():
             for key, blk in self.executed_resblocks():
@@ -234,11 +252,35 @@ class TrajUNet(_HipBlock):
             out["embed_proj.w_time"] = w[:, :128].float().contiguous()
             out["embed_proj.w_attr"] = w[:, 128:].float().contiguous()
             out["embed_proj.b"] = torch.cat([blk.embed_proj.bias.detach() for _, blk in self.executed_resblocks()]).float().contiguous()
-        if hit is not None:
-            # programs hold raw pointers into the old packed tensors
-            self._programs = {k: v for k, v in self._programs.items() if k[2] != dtype}
-        self._packed[dtype] = (ver, out)
         return out
+
+    def packed_weights(self, dtype: torch.dtype, check_data: bool = False) -> Dict[str, torch.Tensor]:
+        """GEMM-layout weights in the compute dtype, refreshed whenever a parameter changes.  A refresh writes INTO the cached
+        tensors, so programs and captured graphs (which hold their addresses) stay valid; only when a parameter's storage
+        moved are the programs (which also hold raw parameter pointers: biases, GroupNorm affine, stem/head) dropped.
+        check_data: also compare the parameters' norms with those at packing time (writes through `.data`)."""
+        ver, ptrs = self._fingerprint()
+        hit = self._packed.get(dtype)
+        if hit is not None and hit[1] != ptrs:
+            self._packed.clear()
+            self._programs.clear()
+            hit = None
+        digest = None
+        stale = hit is None or hit[0] != ver
+        if not stale and check_data:
+            digest = self._data_digest()
+            stale = digest is not None and (hit[2] is None or not torch.equal(digest, hit[2]))
+        if not stale:
+            return hit[3]
+        new = self._build_packed(dtype)
+        if hit is not None:
+            with torch.no_grad():
+                for k, v in new.items():
+                    hit[3][k].copy_(v)
+            new = hit[3]
+        self._packed[dtype] = (ver, ptrs, self._data_digest() if digest is None else digest, new)
+        self.weights_epoch += 1
+        return new
 
     def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> UNetProgram:
         dtype = self.compute_dtype if dtype is None else dtype
@@ -254,6 +296,7 @@ class TrajUNet(_HipBlock):
         super()._apply(fn, *a, **k)
         self._packed.clear()
         self._programs.clear()
+        self.__dict__.pop("_train_steps", None)   # TrainStep programs hold views of the old parameter storage
         return self
 
     def time_bias_table(self, t_values: torch.Tensor) -> torch.Tensor:

@@ -41,8 +41,9 @@ class _HipBlock(nn.Module):
     def _guard(self, *tensors: torch.Tensor) -> None:
         if self.training:
             raise NotImplementedError(
-                f"{type(self).__name__}: the HIP path implements inference (eval mode) only; call .eval() first "
-                "(training-mode dropout + backward kernels are the next row of the build, see DESIGN.md)")
+                f"{type(self).__name__}: a block's stand-alone forward runs in eval mode only; call .eval() first. "
+                "Training (dropout + backward kernels) runs through the whole model: TrajUNet.forward in train() mode "
+                "(trajectorydiffusion_amd/training.py)")
         for t in tensors:
             _lib.require_device(t, f"{type(self).__name__} input")
 

@@ -72,9 +72,10 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
       for (int j = 0; j < 4; ++j) zv[j] = e0 + j < n ? z[e0 + j] : 0.f;
     } else {
       uint32_t r[4];
-      // step_ctr = device int32[4] {step, seed_lo, seed_hi, -}: a seed that can change between graph replays
+      // step_ctr = device int32[4] {step, seed_lo, seed_hi, stream}: a seed that can change between graph replays; the Philox
+      // stream id is step_ctr[3] (the diffusion step t: tdx_step_prepare writes it), so every sampling path draws the same z
       const uint64_t dyn = step_ctr ? (((uint64_t)(uint32_t)step_ctr[2] << 32) | (uint32_t)step_ctr[1]) : 0ull;
-      philox4((uint64_t)(first_elem + e0) >> 2, (uint32_t)(step_ctr ? step_ctr[0] : 0), seed ^ dyn, r);
+      philox4((uint64_t)(first_elem + e0) >> 2, (uint32_t)(step_ctr ? step_ctr[3] : 0), seed ^ dyn, r);
       box_muller(r[0], r[1], zv[0], zv[1]);
       box_muller(r[2], r[3], zv[2], zv[3]);
     }
@@ -122,8 +123,14 @@ __global__ __launch_bounds__(256) void step_prepare_kernel(int* __restrict__ ste
     for (long i = gid; i < B; i += gsz) t_vec[i] = t;
   }
 }
-__global__ void step_advance_kernel(int* __restrict__ step_ctr) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *step_ctr = *step_ctr + 1;
+// step_ctr[3] = Philox stream id of this step's noise = the diffusion step t (or the step index without a step_to_t table)
+__global__ void step_advance_kernel(int* __restrict__ step_ctr, const int* __restrict__ step_to_t, int nsteps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int step = *step_ctr;
+    const int s = step < 0 ? 0 : (step >= nsteps ? nsteps - 1 : step);
+    step_ctr[3] = step_to_t ? step_to_t[s] : s;
+    *step_ctr = step + 1;
+  }
 }
 
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
@@ -192,7 +199,7 @@ extern "C" int tdx_step_prepare(int32_t* step_ctr, const float* coef_table, int3
   hipLaunchKernelGGL(step_prepare_kernel, dim3(blocks), dim3(256), 0, st, step_ctr, coef_table, ncoef, coef_cur, tbias_table, ntb,
                      tbias_cur, step_to_t, t_vec, B, nsteps);
   TDX_CHECK_LAUNCH("step_prepare_kernel");
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, step_ctr);
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, step_ctr, step_to_t, nsteps);
   TDX_CHECK_LAUNCH("step_advance_kernel");
   return TDX_OK;
 }

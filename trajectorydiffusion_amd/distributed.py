@@ -7,10 +7,43 @@ by the GLOBAL sample index: the gathered result equals the unsharded run bit for
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def free_port() -> int:
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous of a one-node job)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_launch_command(script: str, argv: Sequence[str], gpus: int, port: Optional[int] = None, python: Optional[str] = None) -> List[str]:
+    """The child command that runs `script argv...` as `gpus` ranks of ONE node, one rank per GPU over RCCL:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv..."""
+    if gpus < 1:
+        raise ValueError(f"gpus={gpus}")
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port if port is not None else free_port()), script, *argv]
+
+
+def spawn_ranks_if_needed(script: str, argv: Sequence[str], gpus: int) -> Optional[int]:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks as a CHILD process (never an
+    exec: this must also be safe after the GPU has been touched, although callers call it before any GPU call), let the
+    child's stdout/stderr through (rank 0 prints the JSON line) and return its exit code.  Returns None when this process
+    is already a rank (launched by torch.distributed.run) or N == 1: the caller then runs the benchmark itself."""
+    if gpus <= 1 or "RANK" in os.environ:
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL on this image needs dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // gpus))))
+    return subprocess.run(rank_launch_command(script, argv, gpus), env=env).returncode
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -76,3 +109,48 @@ def allreduce_slice_async(piece: torch.Tensor, group: Optional[dist.ProcessGroup
         piece.copy_(host)
         return None
     return dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+# ---- overlap schedule of the gradient exchange (pure host logic: unit-tested on the CPU) ---------------------------------
+
+def scan_gradient_writers(spans: Sequence[Tuple[int, int, str]], launches: Sequence[Sequence], arena_lo: int, arena_hi: int,
+                          folded: Sequence[str] = ()) -> Dict[str, int]:
+    """name -> index of the LAST launch of a recorded program that writes that gradient.
+
+    spans    (address_lo, address_hi, name) of every parameter gradient inside the flat gradient buffer [arena_lo, arena_hi)
+    launches per recorded launch, its argument tuple: any int argument that is an address inside a span marks a write
+             (the program passes raw device pointers, so the schedule cannot drift from what the program really does)
+    folded   names completed only AFTER the program (padded stand-ins folded back): ready index = len(launches)
+    Raises ValueError when some gradient has no writer."""
+    import bisect
+    spans = sorted(spans)
+    starts = [lo for lo, _, _ in spans]
+    ready = {n: -1 for _, _, n in spans}
+    for i, args in enumerate(launches):
+        for a in args:
+            if isinstance(a, int) and not isinstance(a, bool) and arena_lo <= a < arena_hi:
+                k = bisect.bisect_right(starts, a) - 1
+                if k >= 0 and a < spans[k][1]:
+                    ready[spans[k][2]] = i
+    for n in folded:
+        if n in ready:
+            ready[n] = len(launches)
+    missing = [n for n, r in ready.items() if r < 0]
+    if missing:
+        raise ValueError(f"no backward launch writes the gradient of {missing[:3]}")
+    return ready
+
+
+def bucket_plan(spans: Sequence[Tuple[int, int, int]], used: int, bucket_bytes: int, elem_bytes: int = 4) -> List[Tuple[int, int, int]]:
+    """Slices (lo, hi, ready) of a flat gradient buffer of `used` elements, at most bucket_bytes each, sorted by the launch
+    index after which each is complete (ties: by position).  spans = (lo, hi, ready) per gradient, in elements.  The slices
+    cover [0, used) exactly once; a slice is ready when the last gradient overlapping it is (alignment gaps belong to no
+    gradient and are ready at once)."""
+    step = max(64, int(bucket_bytes) // elem_bytes)
+    plan = []
+    for lo in range(0, used, step):
+        hi = min(lo + step, used)
+        rdy = max((r for a, b, r in spans if a < hi and b > lo), default=0)
+        plan.append((lo, hi, rdy))
+    plan.sort(key=lambda t: (t[2], t[0]))
+    return plan

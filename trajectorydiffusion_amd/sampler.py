@@ -38,6 +38,7 @@ class GraphSampler:
         self.coef_table = coef.to(torch.float32).contiguous().to(device)
         self.step_to_t = ts.to(torch.int32).to(device)
         self.tbias_table = model.time_bias_table(ts.to(device))
+        self._epoch = model.weights_epoch
         self.coef_cur = torch.zeros(4, dtype=torch.float32, device=device)
         self.ctr = torch.zeros(4, dtype=torch.int32, device=device)  # {step, seed_lo, seed_hi, -}
         self.zbuf = torch.zeros((B, 2, L), dtype=torch.float32, device=device)
@@ -45,8 +46,16 @@ class GraphSampler:
         self.first_elem = 0
 
     def valid(self) -> bool:
-        self.model.packed_weights(self.model.compute_dtype)
-        return self.model._programs.get(self._prog_key) is self.prog
+        """False when the model dropped this sampler's program (parameters moved, dtype/mode changed).  Weight VALUES may
+        change freely: the packed copies are refreshed in place (also after writes through `.data`, which only the norm
+        digest sees) and the per-step time rows are re-derived."""
+        self.model.packed_weights(self.model.compute_dtype, check_data=True)
+        if self.model._programs.get(self._prog_key) is not self.prog:
+            return False
+        if self.model.weights_epoch != self._epoch:
+            self.tbias_table.copy_(self.model.time_bias_table(self.ts.to(self.device)))
+            self._epoch = self.model.weights_epoch
+        return True
 
     def _step(self, inject: bool) -> None:
         p, st = self.prog, _lib.stream_ptr()
@@ -96,7 +105,7 @@ class GraphSampler:
         p.embed_pg.run()  # attribute half of every embed_proj, once per call
         engine.check_err_flag(p.err, "diffusionBackward")
         seed = self.dm._draw_seed()
-        self.ctr.copy_(torch.tensor([0, seed & 0x7fffffff, (seed >> 31) & 0x7fffffff, 0], dtype=torch.int32))
+        self.ctr.copy_(torch.tensor(self.dm.seed_words(seed), dtype=torch.int32))
         for s in range(self.nsteps):
             t = int(self.ts[s])
             if inject and t > 0:

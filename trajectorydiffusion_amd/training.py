@@ -39,12 +39,22 @@ class _Src:
         return self.W.detach()[:, self.w_off:self.w_off + self.cin, :]
 
 
+def default_dropout_seed() -> int:
+    """Dropout Philox seed when the caller gives none: drawn from torch's CPU generator (so torch.manual_seed controls the masks,
+    and two runs without a manual seed differ) and mixed with the data-parallel rank (ranks that seed torch identically, as DDP
+    scripts do, still draw different masks for their different batch shards)."""
+    import torch.distributed as dist
+    base = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return (base ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
+
+
 class TrainStep:
     """The training step of one (B, L) batch shape: forward and backward programs built once, then
     forward_backward() / optimizer_step() per batch (or forward() + backward() behind torch.autograd, see train_forward)."""
 
     def __init__(self, model, B: int, L: int, device: torch.device, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: int = 0, graph_repack: bool = True):
+                 eps: float = 1e-8, weight_decay: float = 0.01, dropout: Optional[float] = None, seed: Optional[int] = None, graph_repack: bool = True):
         self.m, self.B, self.L, self.dev = model, B, L, device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lib = _lib.lib()
@@ -75,7 +85,7 @@ class TrainStep:
         self.step_count = 0
         self.state: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.dropout = dropout          # None: each ResnetBlock's own p (0.1, TrajUNetBlocks.py:66); 0.0 switches it off
-        self.seed = seed
+        self.seed = default_dropout_seed() if seed is None else int(seed) & ((1 << 64) - 1)
         self.rng = torch.zeros(4, dtype=torch.int32, device=device)   # [0] = forward-pass counter, read by tdx_dropout
         self._passes = 0
         self._layer = 0
@@ -387,25 +397,14 @@ class TrainStep:
         """name -> index of the LAST backward launch that writes that parameter's gradient (len(ops) for gradients that
         are completed by the fold of a padded stand-in after the program).  Found by looking for pointers into the flat
         gradient buffer among the launch arguments, so it cannot drift from what the program really does."""
+        from .distributed import scan_gradient_writers
         base, end = self._garena.data_ptr(), self._garena.data_ptr() + 4 * self._garena_used
-        spans = sorted((g.data_ptr(), g.data_ptr() + 4 * g.numel(), n) for n, g in self.grads.items() if n in self.params)
-        starts = [lo for lo, _, _ in spans]
-        ready = {n: -1 for _, _, n in spans}
-        import bisect
-        for i, (_, _, args) in enumerate(self.bw.ops):
-            for a in args:
-                if isinstance(a, int) and base <= a < end:
-                    k = bisect.bisect_right(starts, a) - 1
-                    if k >= 0 and a < spans[k][1]:
-                        ready[spans[k][2]] = i
-        nops = len(self.bw.ops)
-        for q, p, _, where in self._padded:
-            if self._pname[id(q)] in self.grads:
-                ready[self._pname[id(p)]] = nops
-        missing = [n for n, r in ready.items() if r < 0]
-        if missing:
-            raise TdxError(f"TrainStep: no backward launch writes the gradient of {missing[:3]}")
-        return ready
+        spans = [(g.data_ptr(), g.data_ptr() + 4 * g.numel(), n) for n, g in self.grads.items() if n in self.params]
+        folded = [self._pname[id(p)] for q, p, _, where in self._padded if self._pname[id(q)] in self.grads]
+        try:
+            return scan_gradient_writers(spans, [args for _, _, args in self.bw.ops], base, end, folded)
+        except ValueError as e:
+            raise TdxError(f"TrainStep: {e}") from None
 
     def _bucket_plan(self, bucket_bytes: int) -> List[Tuple[int, int, int]]:
         """(lo, hi, ready) slices of the flat gradient buffer, at most bucket_bytes each, in the order they complete.  The
@@ -413,16 +412,11 @@ class TrainStep:
         key = int(bucket_bytes)
         plan = self._plans.get(key)
         if plan is None:
-            step = max(64, bucket_bytes // 4)
+            from .distributed import bucket_plan
             base = self._garena.data_ptr()
-            spans = sorted(((g.data_ptr() - base) // 4, (g.data_ptr() - base) // 4 + g.numel(), self._grad_ready[n])
-                           for n, g in self.grads.items() if n in self.params)
-            plan = []
-            for lo in range(0, self._garena_used, step):
-                hi = min(lo + step, self._garena_used)
-                rdy = max((r for a, b, r in spans if a < hi and b > lo), default=0)
-                plan.append((lo, hi, rdy))
-            plan.sort(key=lambda t: (t[2], t[0]))
+            spans = [((g.data_ptr() - base) // 4, (g.data_ptr() - base) // 4 + g.numel(), self._grad_ready[n])
+                     for n, g in self.grads.items() if n in self.params]
+            plan = bucket_plan(spans, self._garena_used, bucket_bytes)
             self._plans[key] = plan
         return plan
 
@@ -566,6 +560,18 @@ class TrainStep:
     def named_gradients(self) -> Dict[str, torch.Tensor]:
         return {n: g for n, g in self.grads.items() if n in self.params}
 
+    def set_lr(self, lr: float) -> None:
+        """Learning rate of the next optimizer_step() (a host double handed to tdx_adamw_step per call: a scheduler may change
+        it every iteration, train.ipynb:209)."""
+        lr = float(lr)
+        if not lr >= 0.0:
+            raise ValueError(f"TrainStep.set_lr: lr={lr}")
+        self.lr = lr
+
+    def optimizer(self) -> "FusedAdamW":
+        """A torch.optim.Optimizer whose step() is optimizer_step(): plugs into torch.optim.lr_scheduler.*."""
+        return FusedAdamW(self)
+
     def optimizer_step(self) -> None:
         """torch.optim.AdamW(lr, betas, eps, weight_decay) over every parameter that received a gradient (train.ipynb:131,208)."""
         self.step_count += 1
@@ -578,6 +584,31 @@ class TrainStep:
             _lib.check(self.lib.tdx_adamw_step(p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), self.lr, self.betas[0],
                                                self.betas[1], self.eps, self.wd, self.step_count, st), "tdx_adamw_step")
             torch.autograd.graph.increment_version(p)   # the inference side re-packs its weights when a parameter's version moves
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.Optimizer face of TrainStep.optimizer_step (tdx_adamw_step over every parameter that received a gradient),
+    so that the reference's optimizer-side plumbing runs unchanged: `scheduler = ReduceLROnPlateau(optimizer, factor=0.5,
+    patience=2000)` and `scheduler.step(float(mov_avg_loss))` per iteration (train.ipynb:133,209) write
+    `param_groups[0]['lr']`, and step() hands that value to the kernel.  zero_grad() is a no-op: TrainStep zeroes its
+    gradient arena at the start of every backward pass."""
+
+    def __init__(self, train_step: "TrainStep"):
+        self.ts = train_step
+        super().__init__(list(train_step.params.values()), dict(lr=train_step.lr, betas=train_step.betas, eps=train_step.eps,
+                                                                weight_decay=train_step.wd))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self.ts.set_lr(g["lr"])
+        self.ts.betas, self.ts.eps, self.ts.wd = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.ts.optimizer_step()
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        return None
 
 
 class _TrainForward(torch.autograd.Function):

@@ -19,8 +19,8 @@ BF16_TOL = 1e-2   #             1e-2 in bf16  (relative = max |err| / max |ref| 
 
 # Metre tolerances on the denormalised x0 of the C1 chain (random-init weights: |x0| reaches ~15 z-units, i.e. points ~30 km
 # from the city centre; 1 z-unit = 0.0213 deg lon = 1.96 km, 0.0194 deg lat = 2.15 km at Xi'an).
-FP32_METRES = 15.0
-BF16_METRES = 1500.0
+FP32_METRES = 2.0      # measured 0.70 m (of which ~0.8 m is one fp32 ulp of a longitude near 108.95 degrees)
+BF16_METRES = 500.0    # measured: worst point 198 m, mean 38 m over the 16 x 200 points (0.65 % of the ~30 km extent)
 XIAN_STATS = [21599.4980, 108.950773428688, 34.24354179925547, 12470.9102, 0.02129110045580343, 0.019358855648211895]
 
 

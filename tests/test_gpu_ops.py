@@ -436,7 +436,7 @@ def test_ddpm_update_philox_noise_is_standard_normal_and_shard_invariant():
     lib = _lib.lib()
     n = 1 << 22
     coef = torch.tensor([0.0, 1.0, 1.0], device="cuda")  # x = 0 + 1 * z
-    ctr = torch.tensor([5, 123, 456, 0], dtype=torch.int32, device="cuda")
+    ctr = torch.tensor([5, 123, 456, 5], dtype=torch.int32, device="cuda")   # {step, seed_lo, seed_hi, Philox stream id (= t)}
     zeros = torch.zeros(n, device="cuda")
 
     def draw(first, count, seed=99):
@@ -450,7 +450,15 @@ def test_ddpm_update_philox_noise_is_standard_normal_and_shard_invariant():
     assert torch.equal(torch.cat([draw(0, half), draw(half, half)]), z)  # batch shards draw what the whole batch draws
     assert not torch.equal(draw(0, 1024, seed=100), z[:1024])
     ctr[0] = 6
-    assert not torch.equal(draw(0, 1024), z[:1024])
+    assert torch.equal(draw(0, 1024), z[:1024])          # the step counter itself is not part of the key ...
+    ctr[3] = 6
+    assert not torch.equal(draw(0, 1024), z[:1024])      # ... the stream id (the diffusion step t) is
+    # tdx_step_prepare writes the stream id: step_to_t[step], then advances the step
+    step_to_t = torch.tensor([499, 498, 7], dtype=torch.int32, device="cuda")
+    coef_tab = torch.zeros(3, 4, device="cuda"); coef_cur = torch.zeros(4, device="cuda")
+    c2 = torch.tensor([2, 0, 0, 0], dtype=torch.int32, device="cuda")
+    _lib.check(lib.tdx_step_prepare(c2.data_ptr(), coef_tab.data_ptr(), 4, coef_cur.data_ptr(), None, 0, None, step_to_t.data_ptr(), None, 0, 3, _lib.stream_ptr()))
+    assert c2.tolist() == [3, 0, 0, 7]
 
 
 def test_q_sample():

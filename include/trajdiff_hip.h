@@ -185,6 +185,15 @@ int64_t tdx_train_workspace_floats(void);
  * dpred[i] = 2 (pred[i] - target[i]) / n (dpred may be null). */
 int tdx_mse_loss_grad(const float* pred, const float* target, float* dpred, float* loss, int64_t n, float* ws, void* stream);
 
+/* tdx_mse_loss_grad without a workspace argument and without any allocation.  No counterpart in the reference: it exists for
+ * callers that cannot allocate or pass scratch memory (code under HIP graph capture, tight serving/training loops, harnesses
+ * that forbid hipMalloc).  The first-stage partial sums live in a 4 KiB file-scope device array of the library (one copy per
+ * GPU, held until the process ends); n <= 2^28 elements, larger inputs are rejected with TDX_ERR_ARG.  Same kernels and
+ * launch geometry as tdx_mse_loss_grad: results are bit-identical to it.  Calls that overlap on ONE GPU (two streams, two
+ * threads) share that GPU's array and race; serialise them.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress): make that call outside graph capture. */
+int tdx_mse_loss_grad_static(const float* pred, const float* target, float* dpred, float* loss, int64_t n, void* stream);
+
 /* out[c] (+)= sum over the n rows of x[r * ld + c], c < C <= 4096: bias gradients of Conv1d / Linear, and dgamma / dbeta from the
  * per-trajectory rows of tdx_groupnorm_act_bwd. */
 int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int32_t accumulate, int32_t dtype, float* ws, void* stream);

@@ -707,6 +707,46 @@ extern "C" int tdx_mse_loss_grad(const float* pred, const float* target, float* 
   return TDX_OK;
 }
 
+// ---- the one entry point that allocates nothing (no reference counterpart; for callers that cannot allocate) --------------
+// tdx_mse_loss_grad with its first-stage partial sums in a file-scope device array instead of a caller workspace.
+// `g_mse_scratch` is, in host code, only a stand-in for the symbol: the device address is asked for once per device with
+// hipGetSymbolAddress (each GPU holds its own copy of the array) and that pointer is what every kernel argument uses.
+constexpr int64_t kStaticMaxN = (int64_t)1 << 28;    // elements per operand (1 GiB of fp32); 4 KiB of scratch per GPU
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) float g_mse_scratch[kRedBlocks];
+static float* g_mse_scratch_ptr[kMaxDevices] = {};   // per device, filled on the first call made with that device current
+
+static int static_scratch(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) TDX_FAIL(TDX_ERR_HIP, "tdx_mse_loss_grad_static: no current device (or index >= %d)", kMaxDevices);
+  float* p = __atomic_load_n(&g_mse_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (p == nullptr) {
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_mse_scratch));
+    if (e != hipSuccess || sym == nullptr) TDX_FAIL(TDX_ERR_HIP, "tdx_mse_loss_grad_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+    p = (float*)sym;
+    __atomic_store_n(&g_mse_scratch_ptr[dev], p, __ATOMIC_RELEASE);   // (two threads racing here store the same address)
+  }
+  *out = p;
+  return TDX_OK;
+}
+
+extern "C" int tdx_mse_loss_grad_static(const float* pred, const float* target, float* dpred, float* loss, int64_t n, void* stream) {
+  TDX_CHECK_ARG(pred && target && loss && n > 0, "tdx_mse_loss_grad_static: null pointer or empty input");
+  TDX_CHECK_ARG(n <= kStaticMaxN, "tdx_mse_loss_grad_static: n=%lld exceeds the static scratch's limit of %lld elements; use tdx_mse_loss_grad with a workspace",
+                (long long)n, (long long)kStaticMaxN);
+  float* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != TDX_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  // every partial the second kernel reads is written by the first one of THIS call: nothing has to start at zero
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, ws, (long)n, 2.0f / (float)n);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, blocks, loss, 1.0f / (float)n);
+  TDX_CHECK_LAUNCH("mse_loss_grad_static");
+  return TDX_OK;
+}
+
 extern "C" int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int32_t accumulate, int32_t dtype, float* ws, void* stream) {
   TDX_CHECK_ARG(x && out && ws && n > 0 && c > 0 && ld >= c, "tdx_colsum: bad arguments n=%d c=%d ld=%d", n, c, ld);
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_colsum: bad dtype %d", dtype);

@@ -54,6 +54,17 @@ typedef struct {
   int32_t reserved;
 } tdx_kseg;
 
+/* GroupNorm(+act) applied to ONE K-segment while tdx_conv_gemm loads it; see tdx_conv_desc.norm. */
+typedef struct {
+  const float* mr;      /* (B, mr_ld, 2) fp32 {rstd, -mean * rstd} per (trajectory, group), from tdx_groupnorm_finalize; or NULL */
+  const float* gamma;   /* [cin]: affine parameters of the segment's channels */
+  const float* beta;
+  int32_t cpg;          /* channels per group: a power of two >= 4 */
+  int32_t act;          /* TDX_ACT_* applied after the affine */
+  int32_t mr_ld;        /* groups per trajectory row of `mr` */
+  int32_t mr_off;       /* group that holds the segment's channel 0 */
+} tdx_seg_norm;
+
 /* Conv1d (k=3 / k=1, stride 1/2, optional nearest-upsampled input, optional channel-concat of
  * several sources, optional fused 1x1 shortcut as an extra segment) as ONE gathered GEMM on MFMA:
  *   out[n, co] = act( sum_seg sum_t sum_ci  w[co, k(seg,t,ci)] * src_seg[row(n,t), ch_off+ci]
@@ -97,11 +108,30 @@ typedef struct {
    * reproducible, but the fp32 summation order differs from the unsplit kernels (and so may the last bit).  NULL = never. */
   void* ws;
   int64_t ws_bytes;
+  /* Optional GroupNorm(+act) of the INPUT of segment i, applied while the segment is loaded (norm[i].mr != NULL):
+   *   x'[b, l, c] = norm_act((x[b, l, c] - mean[b, g]) * rstd[b, g] * gamma[c] + beta[c]),  g = c / cpg (c counted from the
+   * segment's channel 0 inside the normalised tensor, i.e. gamma/beta/stats already point at that channel),
+   * with rstd and -mean * rstd read from norm[i].mr (tdx_groupnorm_finalize turns the block partial sums that the PRODUCER of
+   * x wrote through its stats_out into that table).  The conv's zero
+   * padding applies to x' (as in the reference, where the padding pads the normalised tensor).  This replaces the
+   * nn.GroupNorm + Swish that PRECEDES a conv (Models/TrajUNetBlocks.py:75-77, :83-86) without a normalised copy in memory.
+   * Only some shapes support it: ask tdx_conv_gemm_norm_fusable() first. */
+  tdx_seg_norm norm[4];
+  /* Optional statistics of the OUTPUT for a later consumer's norm[]: for every trajectory b, 16-row block j = l / 16 and
+   * 4-channel granule q = co / 4, stats_out[((b * ceil(lout / 16) + j) * stats_out_ld + stats_out_off + q) * 2 + {0, 1}] =
+   * {sum, sum of squares} of the finished fp32 values out[b, 16 j .. 16 j + 15, 4 q .. 4 q + 3] (fixed summation order per
+   * block: bitwise reproducible and independent of the batch size).  NULL = none. */
+  float* stats_out;
+  int32_t stats_out_ld, stats_out_off;
 } tdx_conv_desc;
 int tdx_conv_gemm(const tdx_conv_desc* host_desc, void* stream);
 /* 1 if tdx_conv_gemm can run this descriptor WITH its fused GroupNorm, 0 if the caller must run
  * tdx_groupnorm_act separately (trajectories longer than a 256-row tile, odd channel counts, ...). */
 int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* host_desc);
+/* 1 if tdx_conv_gemm can run this descriptor WITH its norm[] / stats_out fields (today: bf16, one 128-channel k=3 segment,
+ * 128 output channels, enough rows to fill the chip: the HBM-bound full-resolution layers, where a separate GroupNorm pass
+ * costs as much as the conv), 0 if the caller must run tdx_groupnorm_act separately and leave those fields empty. */
+int tdx_conv_gemm_norm_fusable(const tdx_conv_desc* host_desc);
 
 /* GroupNorm(groups, C, eps, affine) [+ Swish] over channels-last rows, one pass to memory:
  *   out[b, l, out_off + c] = act((x[b,l,c] - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c])
@@ -111,10 +141,30 @@ int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, in
                       const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
                       int32_t groups, float eps, int32_t act, int32_t dtype, void* stream);
 
+/* Second half of the split GroupNorm: block partial sums (tdx_conv_desc.stats_out, tdx_stem_conv_stats) -> per (trajectory, group)
+ *   mr[b, mr_off + g] = {rstd, -mean * rstd},  mean / biased variance over the L rows x cpg channels of group g
+ * (g < groups; group g = granules [g * cpg / 4, (g + 1) * cpg / 4) of stats starting at granule stats_off; blocks and granules
+ * are added in a fixed order, in double).  stats is (B, ceil(L / 16), stats_ld, 2) fp32, mr is (B, mr_ld, 2) fp32.
+ * Replaces the statistics half of nn.GroupNorm (Models/TrajUNetBlocks.py:75,83; Models/TrajUNet.py:43). */
+int tdx_groupnorm_finalize(const float* stats, int32_t stats_ld, int32_t stats_off, float* mr, int32_t mr_ld, int32_t mr_off,
+                           int32_t B, int32_t L, int32_t groups, int32_t cpg, float eps, void* stream);
+
 /* Stem Conv1d(2 -> C0, k3, p1): x (B, 2, L) fp32 channels-first -> out (B, L, C0) rows.
  * w is the reference layout (C0, 2, 3) fp32.  Replaces Models/TrajUNet.py:21,107. */
 int tdx_stem_conv(const float* x, const float* w, const float* bias, void* out, int32_t B, int32_t L,
                   int32_t C0, int32_t dtype, void* stream);
+
+/* tdx_stem_conv (bf16 output) that also writes the block partial sums of its output, in the layout of tdx_conv_desc.stats_out,
+ * for the GroupNorm that follows the stem (Models/TrajUNetBlocks.py:75 of down_blocks.0.0).  C0 % 32 == 0. */
+int tdx_stem_conv_stats(const float* x, const float* w, const float* bias, void* out, float* stats, int32_t stats_ld,
+                        int32_t stats_off, int32_t B, int32_t L, int32_t C0, void* stream);
+
+/* Head GroupNorm + Conv1d in one pass over the RAW rows x (B, L, C0) bf16: a = (x * rstd + (-mean * rstd)) * gamma + beta from
+ * the {rstd, -mean * rstd} table of tdx_groupnorm_finalize, then the k3 conv to (B, 2, L) fp32.  Replaces Models/TrajUNet.py:42-45,112
+ * without a normalised copy in memory.  C0 a power of two <= 512. */
+int tdx_head_conv_norm(const void* x, const float* mr, int32_t mr_ld, int32_t mr_off, int32_t cpg, const float* gamma,
+                       const float* beta, const float* w, const float* bias, float* out, int32_t B, int32_t L, int32_t C0,
+                       void* stream);
 
 /* Head Conv1d(C0 -> 2, k3, p1) on already group-normalised rows a (B, L, C0) -> eps (B, 2, L)
  * fp32 channels-first.  w is (2, C0, 3) fp32.  Replaces Models/TrajUNet.py:44,112. */

@@ -67,15 +67,37 @@ class UNetProgram:
             lens.append(engine.conv_out_len(lens[-1], 2))
         # stem (reference TrajUNet.py:107); only its LENGTH is used as a skip (:109 + :93)
         cur = pg.alloc((B, L, cs[0]))
-        pg.call("stem", pg.lib.tdx_stem_conv, self.x.data_ptr(), engine.fp32_param(m.stem.weight, "stem.weight").data_ptr(),
-                engine.fp32_param(m.stem.bias, "stem.bias").data_ptr(), cur.data_ptr(), B, L, cs[0], pg.code, keep=[cur])
-        gn_in = engine.block_input_gn(pg, m.down_blocks[0][0], "down_blocks.0.0.", B, L)
-        engine.emit_groupnorm(pg, cur, cs[0], B, L, gn_in, "down_blocks.0.0.gn1")
+        stem_w, stem_b = engine.fp32_param(m.stem.weight, "stem.weight"), engine.fp32_param(m.stem.bias, "stem.bias")
+        # Split GroupNorm on the first encoder level when its convs are HBM-bound 128 -> 128 layers the library can run that way
+        # (engine.FUSE_NORM_DEFAULT): the stem and every conv leave block partial sums, the consumers normalise on load.
+        split0 = (not m.low_latency and cs[0] == cs[1] and cs[0] % 32 == 0 and cs[0] // 32 >= 4
+                  and engine.norm_fusable_shape(pg, B, L, L, cs[0], cs[1]))
         downs: List[torch.Tensor] = []
         cur_is_skip = False  # skip tensors stay live until the decoder has consumed them
+        if split0:
+            st0 = pg.alloc((B, (L + 15) // 16, cs[0] // 4, 2), torch.float32)
+            pg.call("stem", pg.lib.tdx_stem_conv_stats, self.x.data_ptr(), stem_w.data_ptr(), stem_b.data_ptr(), cur.data_ptr(), st0.data_ptr(),
+                    cs[0] // 4, 0, B, L, cs[0], keep=[cur, st0])
+            g1 = m.down_blocks[0][0].stage1[0]
+            cur_mr = engine.emit_finalize(pg, st0, B, L, g1.num_groups, cs[0] // g1.num_groups, g1.eps, "stem.norm")
+            pg.release(st0)
+            for j in range(R):
+                key = f"down_blocks.0.{j}."
+                nxt_eps = m.down_blocks[0][j + 1].stage1[0].eps if j + 1 < R else None
+                nxt, nxt_mr = engine.emit_resblock_split_norm(pg, m.down_blocks[0][j], packed, key, cur, cur_mr, B, L, eb, tb, NE,
+                                                              m.embed_offsets[key], nxt_eps)
+                pg.release(cur)
+                pg.release(cur_mr)
+                cur, cur_mr = nxt, nxt_mr
+            gn_in = None
+        else:
+            pg.call("stem", pg.lib.tdx_stem_conv, self.x.data_ptr(), stem_w.data_ptr(), stem_b.data_ptr(), cur.data_ptr(), B, L, cs[0], pg.code,
+                    keep=[cur])
+            gn_in = engine.block_input_gn(pg, m.down_blocks[0][0], "down_blocks.0.0.", B, L)
+            engine.emit_groupnorm(pg, cur, cs[0], B, L, gn_in, "down_blocks.0.0.gn1")
         for i in range(m.stages):  # encoder, :65-78
             li, co = lens[i], cs[i + 1]
-            for j in range(R):
+            for j in range(R if not (split0 and i == 0) else 0):
                 key = f"down_blocks.{i}.{j}."
                 blk = m.down_blocks[i][j]
                 nxt_gn = engine.block_input_gn(pg, m.down_blocks[i][j + 1], f"down_blocks.{i}.{j + 1}.", B, li) if j + 1 < R else None
@@ -131,6 +153,23 @@ class UNetProgram:
             cur = srcs[0][0]
             uconv = m.up_blocks[i][R]
             last = i + 1 == m.stages
+            head_split = (last and not m.low_latency and co % 32 == 0 and co // m.head[0].num_groups >= 4 and (co & (co - 1)) == 0 and co <= 512
+                          and engine.norm_fusable_shape(pg, B, li, lo, co, co, norm=False, stats=True))
+            if head_split:
+                # the last up conv leaves the block sums of its output; the head conv applies the head GroupNorm while it loads
+                gn_head, hconv = m.head[0], m.head[1]
+                nxt = pg.alloc((B, lo, co))
+                st_h = pg.alloc((B, (lo + 15) // 16, co // 4, 2), torch.float32)
+                pg.conv([engine.Seg(cur, co, co, li, lvirt=lo)], packed[f"up_blocks.{i}.up.w"],
+                        engine.fp32_param(uconv.bias, f"up_blocks.{i}.{R}.bias"), nxt, co, B, lo, co, name=f"up_blocks.{i}.up", stats_out=st_h)
+                pg.release(cur)
+                cpg_h = co // gn_head.num_groups
+                mr_h = engine.emit_finalize(pg, st_h, B, lo, gn_head.num_groups, cpg_h, gn_head.eps, "head.norm")
+                pg.call("head.conv", pg.lib.tdx_head_conv_norm, nxt.data_ptr(), mr_h.data_ptr(), gn_head.num_groups, 0, cpg_h,
+                        engine.fp32_param(gn_head.weight, "head.0.weight").data_ptr(), engine.fp32_param(gn_head.bias, "head.0.bias").data_ptr(),
+                        engine.fp32_param(hconv.weight, "head.1.weight").data_ptr(), engine.fp32_param(hconv.bias, "head.1.bias").data_ptr(),
+                        self.eps.data_ptr(), B, L, cs[0], keep=[nxt, mr_h])
+                return
             if last:  # head GroupNorm (default eps 1e-5, no activation, TrajUNet.py:42-45): the raw tensor is not needed
                 gn_head = m.head[0]
                 a_head = pg.alloc((B, lo, co))

@@ -24,12 +24,17 @@ class KSeg(C.Structure):
                 ("stride", _i32), ("lin", _i32), ("lvirt", _i32), ("reserved", _i32)]
 
 
+class SegNorm(C.Structure):
+    _fields_ = [("mr", _vp), ("gamma", _vp), ("beta", _vp), ("cpg", _i32), ("act", _i32), ("mr_ld", _i32), ("mr_off", _i32)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("seg", KSeg * 4), ("nseg", _i32), ("dtype", _i32), ("w", _vp), ("bias", _vp), ("ebias", _vp),
                 ("tbias", _vp), ("ebias_ld", _i32), ("ebias_off", _i32), ("res", _vp), ("res_ld", _i32), ("act", _i32),
                 ("out", _vp), ("out_ld", _i32), ("out_off", _i32), ("B", _i32), ("lout", _i32), ("cout", _i32),
                 ("reserved", _i32), ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_ld", _i32), ("gn_off", _i32),
-                ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32), ("ws", _vp), ("ws_bytes", _i64)]
+                ("gn_act", _i32), ("gn_cpg", _i32), ("gn_eps", _f32), ("reserved2", _i32), ("ws", _vp), ("ws_bytes", _i64),
+                ("norm", SegNorm * 4), ("stats_out", _vp), ("stats_out_ld", _i32), ("stats_out_off", _i32)]
 
 
 class PackDesc(C.Structure):
@@ -43,10 +48,14 @@ _SIGNATURES = {
     "tdx_device_ok": (_i32, []),
     "tdx_conv_gemm": (_i32, [C.POINTER(ConvDesc), _vp]),
     "tdx_conv_gemm_gn_fusable": (_i32, [C.POINTER(ConvDesc)]),
+    "tdx_conv_gemm_norm_fusable": (_i32, [C.POINTER(ConvDesc)]),
     "tdx_conv_gemm_force_small": (_i32, [_i32]),
     "tdx_conv_gemm_debug": (_i32, [_i32]),
     "tdx_groupnorm_act": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "tdx_groupnorm_finalize": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "tdx_stem_conv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_stem_conv_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tdx_head_conv_norm": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "tdx_head_conv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tdx_attention": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tdx_embed_gather": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -1718,6 +1718,11 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
   const int rc = plan_conv(d, a, ch);
   if (rc != TDX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  {  // 128 -> 128, k = 3 layers (and every descriptor that carries norm[] / stats_out): narrow_conv.hip
+    int handled = 0;
+    const int nrc = tdx_narrow_conv_try(d, st, cu_count(), &handled);
+    if (nrc != TDX_OK || handled) return nrc;
+  }
   if (ch.kind != 0) return d->dtype == TDX_F32 ? run_dma<float>(a, ch, st) : run_dma<__bf16>(a, ch, st);
   // Few tiles and a long K loop (small batches): cut K into slices that run as concurrent workgroups, if the caller gave room.
   const int64_t tiles128 = (int64_t)((a.N + 127) / 128) * ((a.cout + 127) / 128);
@@ -1739,8 +1744,16 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
 // force bits: 1 = never use the LDS-DMA kernels, 2 = never use the window variant, 4 = report GroupNorm as not fusable,
 //             8 = never use the 128-row (two workgroups per CU) tiles, 16 = no tail split, 32 = one tile per workgroup
 //             (no persistent kernel), 64 = never split K, 128 = 128-channel tiles for every Cout;
-//             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation).
+//             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation);
+//             bit 16 = never take the narrow (128 -> 128, k = 3) kernel of narrow_conv.hip.
+extern "C" int tdx_conv_gemm_norm_fusable(const tdx_conv_desc* d) {
+  ConvArgs a;
+  Choice ch;
+  return d && plan_conv(d, a, ch) == TDX_OK && tdx_narrow_conv_ok(d) ? 1 : 0;
+}
+
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
+  tdx_narrow_conv_disable((bits >> 16) & 1);
   g_force = bits & 0xff;
   g_tail_max = (bits >> 8) & 0xff ? ((bits >> 8) & 0xff) * 2 : 128;
   return TDX_OK;

@@ -124,7 +124,46 @@ void launch_gn(int nit, dim3 grid, hipStream_t st, const void* x, int x_ld, void
 #undef TDX_GN
 }
 
+// Split GroupNorm, second half: block partial sums -> {rstd, -mean * rstd} per (trajectory, group).  One thread per entry; the
+// 32 groups of a (trajectory, block) row are adjacent in memory, so a wave reads whole 256-byte rows.
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __restrict__ stats, int stats_ld, int stats_off,
+                                                                float* __restrict__ mr, int mr_ld, int mr_off, int B, int nblk,
+                                                                int groups, int gpg, double inv_cnt, float eps) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)B * groups) return;
+  const int b = (int)(e / groups), g = (int)(e - (long)b * groups);
+  const float* row = stats + (((size_t)b * nblk) * stats_ld + stats_off + (size_t)g * gpg) * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k)          // fixed order: blocks, then granules
+    for (int q = 0; q < gpg; ++q) {
+      const float2 v = *reinterpret_cast<const float2*>(row + ((size_t)k * stats_ld + q) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  const double mean = s1 * inv_cnt;
+  double var = s2 * inv_cnt - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  *reinterpret_cast<float2*>(mr + ((size_t)b * mr_ld + mr_off + g) * 2) = make_float2(rstd, (float)(-mean * (double)rstd));
+}
+
 }  // namespace
+
+extern "C" int tdx_groupnorm_finalize(const float* stats, int32_t stats_ld, int32_t stats_off, float* mr, int32_t mr_ld, int32_t mr_off,
+                                      int32_t B, int32_t L, int32_t groups, int32_t cpg, float eps, void* stream) {
+  TDX_CHECK_ARG(stats && mr && B > 0 && L > 0 && groups > 0, "tdx_groupnorm_finalize: bad arguments");
+  TDX_CHECK_ARG(cpg >= 4 && cpg % 4 == 0, "tdx_groupnorm_finalize: cpg=%d must be a multiple of 4 (statistics come in 4-channel granules)", cpg);
+  const int gpg = cpg / 4;
+  TDX_CHECK_ARG(stats_off >= 0 && stats_off + groups * gpg <= stats_ld && mr_off >= 0 && mr_off + groups <= mr_ld,
+                "tdx_groupnorm_finalize: groups do not fit (stats_ld=%d off=%d, mr_ld=%d off=%d, groups=%d, cpg=%d)", stats_ld, stats_off, mr_ld,
+                mr_off, groups, cpg);
+  TDX_CHECK_ARG(((uintptr_t)stats & 7) == 0 && ((uintptr_t)mr & 7) == 0, "tdx_groupnorm_finalize: 8-byte alignment");
+  const long n = (long)B * groups;
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, stats_ld,
+                     stats_off, mr, mr_ld, mr_off, B, (L + 15) / 16, groups, gpg, 1.0 / ((double)cpg * (double)L), eps);
+  TDX_CHECK_LAUNCH("groupnorm_finalize_kernel");
+  return TDX_OK;
+}
 
 extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
                                  const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,

@@ -30,6 +30,11 @@ void tdx_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) TDX_FAIL(TDX_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// ---- the narrow (128 -> 128, k = 3) conv kernel of narrow_conv.hip, entered through tdx_conv_gemm ------------------------------
+int tdx_narrow_conv_try(const tdx_conv_desc* d, hipStream_t st, int cus, int* handled);
+bool tdx_narrow_conv_ok(const tdx_conv_desc* d);
+void tdx_narrow_conv_disable(int off);
+
 // ---- element traits -----------------------------------------------------------------------
 template <typename T>
 struct Elem;

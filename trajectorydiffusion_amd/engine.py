@@ -17,6 +17,13 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_SWISH, ConvDesc, TdxError
 
 
 FUSE_GN_DEFAULT = False
+# Split GroupNorm on the full-resolution 128-channel level (bf16 programs): producers leave block partial sums (stats_out),
+# tdx_groupnorm_finalize turns them into {rstd, -mean * rstd}, and the consuming conv normalises + activates its input while it
+# loads it (tdx_conv_desc.norm): no stand-alone GroupNorm pass and no normalised copy of those activations in memory.
+# Measured on MI355X (profiles/r2_split_norm_ablation.txt): the fused level costs 0.99 ms per denoise step against 1.02 ms for
+# conv + stand-alone GroupNorm, because the fused conv is bound by vector-ALU issue (the Swish of the transform plus per-tile
+# bookkeeping next to 96 MFMAs per wave), not by HBM.  Correct, deterministic and tested, but not a win yet: off by default.
+FUSE_NORM_DEFAULT = False
 
 
 def conv_out_len(l: int, stride: int) -> int:
@@ -109,6 +116,7 @@ class Program:
         # GroupNorm pass (full-chip HBM stream) beats a longer, un-overlapped epilogue on every TrajUNet shape
         # (profiles/r1_gn_fusion_ablation.txt), so programs use it only on request.
         self.fuse_gn = FUSE_GN_DEFAULT
+        self.fuse_norm = FUSE_NORM_DEFAULT
         # fp32 workspace that lets tdx_conv_gemm cut K into concurrent slices when a conv has too few tiles to fill the chip
         # (small batches); shared by every conv of the program (they run one after the other on one stream).  None = never.
         self.split_k_ws: Optional[torch.Tensor] = None
@@ -137,7 +145,8 @@ class Program:
     def conv(self, segs: Sequence[Seg], w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor], out_ld: int,
              B: int, lout: int, cout: int, out_off: int = 0, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
              res_ld: int = 0, ebias: Optional[torch.Tensor] = None, tbias: Optional[torch.Tensor] = None, ebias_ld: int = 0,
-             ebias_off: int = 0, dtype_code: Optional[int] = None, name: str = "conv", gn: Optional["GnSpec"] = None) -> None:
+             ebias_off: int = 0, dtype_code: Optional[int] = None, name: str = "conv", gn: Optional["GnSpec"] = None,
+             norm: Optional["NormIn"] = None, stats_out: Optional[torch.Tensor] = None) -> None:
         """Record one tdx_conv_gemm.  `gn` = the consumer's GroupNorm(+act): fused into the conv epilogue when the library
         can (then `out` may be None = the raw tensor is not needed), else run as a separate tdx_groupnorm_act."""
         d = ConvDesc()
@@ -158,6 +167,16 @@ class Program:
         d.res, d.res_ld, d.act = _lib.ptr(res), res_ld, act
         d.out, d.out_ld, d.out_off = _lib.ptr(out), out_ld, out_off
         d.B, d.lout, d.cout = B, lout, cout
+        if norm is not None:   # GroupNorm(+act) of segment 0, applied while it is loaded
+            n0 = d.norm[0]
+            n0.mr, n0.gamma, n0.beta = norm.mr.data_ptr(), norm.gamma.data_ptr() + 4 * norm.p_off, norm.beta.data_ptr() + 4 * norm.p_off
+            n0.cpg, n0.act, n0.mr_ld, n0.mr_off = norm.cpg, norm.act, norm.mr.shape[1], norm.mr_off
+            self.keep.extend([norm.mr, norm.gamma, norm.beta])
+        if stats_out is not None:   # (B, ceil(lout / 16), granules, 2) fp32 block partial sums of the output
+            d.stats_out, d.stats_out_ld, d.stats_out_off = stats_out.data_ptr(), stats_out.shape[2], 0
+            self.keep.append(stats_out)
+        if (norm is not None or stats_out is not None) and not self.lib.tdx_conv_gemm_norm_fusable(C.byref(d)):
+            raise TdxError(f"{name}: this shape cannot take norm-on-load / stats_out (ask norm_fusable() before recording it)")
         fused, tmp = False, None
         if gn is not None:
             d.gn_gamma, d.gn_beta = gn.gamma.data_ptr() + 4 * gn.p_off, gn.beta.data_ptr() + 4 * gn.p_off
@@ -222,6 +241,76 @@ def fp32_param(p: torch.Tensor, name: str) -> torch.Tensor:
     if p.dtype != torch.float32 or not p.is_contiguous():
         raise TdxError(f"parameter {name} must be contiguous fp32 (got {p.dtype}); keep master weights in fp32")
     return p.detach()
+
+
+class NormIn:
+    """GroupNorm(+act) that a conv applies to its input while loading it: the {rstd, -mean * rstd} table `mr` (B, groups, 2) written
+    by tdx_groupnorm_finalize from the producer's block partial sums, and the affine parameters (first channel p_off)."""
+    __slots__ = ("mr", "mr_off", "gamma", "beta", "p_off", "cpg", "act")
+
+    def __init__(self, gn_module, name: str, mr: torch.Tensor, cpg: int, act: int, p_off: int = 0, mr_off: int = 0):
+        self.gamma, self.beta = fp32_param(gn_module.weight, name + ".weight"), fp32_param(gn_module.bias, name + ".bias")
+        self.mr, self.mr_off, self.p_off, self.cpg, self.act = mr, mr_off, p_off, cpg, act
+
+
+def norm_fusable_shape(pg: "Program", B: int, lin: int, lout: int, cin: int, cout: int, norm: bool = True, stats: bool = True,
+                       stride: int = 1) -> bool:
+    """Can a (cin -> cout, k=3) conv of this program take norm-on-load (`norm`) and / or emit block statistics (`stats`)?  Asks the
+    library with a representative descriptor (today: bf16, 128 -> 128 channels; norm-on-load on un-resampled stride-1 sources)."""
+    if pg.dtype != torch.bfloat16 or cin % 8 or cout % 8 or not getattr(pg, "fuse_norm", False):
+        return False
+    d = ConvDesc()
+    k = d.seg[0]
+    probe = torch.empty(64, device=pg.device, dtype=pg.dtype)
+    lvirt = lin if stride == 2 or lin == lout else lout
+    k.src, k.src_ld, k.ch_off, k.cin, k.taps, k.stride, k.lin, k.lvirt = probe.data_ptr(), cin, 0, cin, 3, stride, lin, lvirt
+    k.up_scale = float(torch.tensor(float(lin), dtype=torch.float32) / torch.tensor(float(lvirt), dtype=torch.float32))
+    d.nseg, d.dtype, d.w, d.out, d.out_ld, d.B, d.lout, d.cout = 1, pg.code, probe.data_ptr(), probe.data_ptr(), cout, B, lout, cout
+    if stats:
+        d.stats_out, d.stats_out_ld = probe.data_ptr(), cout // 4
+    if norm:
+        cpg = max(4, cin // 32)
+        d.norm[0].mr, d.norm[0].gamma, d.norm[0].beta = probe.data_ptr(), probe.data_ptr(), probe.data_ptr()
+        d.norm[0].cpg, d.norm[0].act, d.norm[0].mr_ld = cpg, ACT_SWISH, cin // cpg
+    return bool(pg.lib.tdx_conv_gemm_norm_fusable(C.byref(d)))
+
+
+def emit_finalize(pg: "Program", stats: torch.Tensor, B: int, L: int, groups: int, cpg: int, eps: float, name: str) -> torch.Tensor:
+    """tdx_groupnorm_finalize: block partial sums (B, ceil(L/16), granules, 2) -> {rstd, -mean * rstd} table (B, groups, 2)."""
+    mr = pg.alloc((B, groups, 2), torch.float32)
+    pg.call(name, pg.lib.tdx_groupnorm_finalize, stats.data_ptr(), stats.shape[2], 0, mr.data_ptr(), groups, 0, B, L, groups, cpg, float(eps),
+            keep=[stats, mr])
+    return mr
+
+
+def emit_resblock_split_norm(pg: "Program", blk, packed: Dict[str, torch.Tensor], key: str, x: torch.Tensor, x_mr: torch.Tensor, B: int, L: int,
+                             ebias: Optional[torch.Tensor], tbias: Optional[torch.Tensor], e_ld: int, e_off: int,
+                             next_eps: Optional[float]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """ResnetBlock (Models/TrajUNetBlocks.py:92-99, in_c == out_c, no 1x1 shortcut) with both GroupNorm+Swish applied inside the
+    convs that consume them: conv1 reads the raw x and normalises it on load (x_mr), leaves the raw h and its block sums;
+    conv2 reads the raw h the same way, adds x, and (next_eps given) leaves the block sums of its output for the next consumer.
+    Returns (raw output, its {rstd, -mean * rstd} table or None)."""
+    c = blk.out_c
+    if blk.in_c != c or blk.has_shortcut:
+        raise TdxError(f"{key}: split-norm dataflow needs in_c == out_c")
+    groups, cpg = blk.norm_groups, c // blk.norm_groups
+    conv1, gn1, gn2, conv2 = blk.stage1[2], blk.stage1[0], blk.stage2[0], blk.stage2[3]
+    nblk = (L + 15) // 16
+    h = pg.alloc((B, L, c))
+    h_stats = pg.alloc((B, nblk, c // 4, 2), torch.float32)
+    pg.conv([Seg(x, c, c, L)], packed[key + "conv1.w"], fp32_param(conv1.bias, key + "stage1.2.bias"), h, c, B, L, c, ebias=ebias, tbias=tbias,
+            ebias_ld=e_ld, ebias_off=e_off, name=key + "conv1", norm=NormIn(gn1, key + "stage1.0", x_mr, cpg, ACT_SWISH), stats_out=h_stats)
+    h_mr = emit_finalize(pg, h_stats, B, L, groups, cpg, gn2.eps, key + "conv1.norm")
+    out = pg.alloc((B, L, c))
+    o_stats = pg.alloc((B, nblk, c // 4, 2), torch.float32) if next_eps is not None else None
+    pg.conv([Seg(h, c, c, L)], packed[key + "conv2.w"], fp32_param(conv2.bias, key + "stage2.3.bias"), out, c, B, L, c, res=x, res_ld=c,
+            name=key + "conv2", norm=NormIn(gn2, key + "stage2.0", h_mr, cpg, ACT_SWISH), stats_out=o_stats)
+    o_mr = emit_finalize(pg, o_stats, B, L, groups, cpg, next_eps, key + "conv2.norm") if next_eps is not None else None
+    for t in (h, h_stats, h_mr):
+        pg.release(t)
+    if o_stats is not None:
+        pg.release(o_stats)
+    return out, o_mr
 
 
 class GnSpec:

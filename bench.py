@@ -2,6 +2,7 @@
 """Headline benchmark: trajectories/sec, TrajUNet 500-step DDPM sampling, L=200 (BASELINE.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--batch B] [--T 500]
+    python bench.py --workload c5      # the latent path: VAE_InvTrans.encode -> SDUNet_CAR 500-step sampling -> decode (L=199)
 
 `--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`, spawned before
@@ -25,27 +26,36 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 SCHEDULE = [128, 128, 256, 512, 1024]
+SD_SCHEDULE = [128, 256, 512, 1024]      # eval_sd.ipynb: SDUNet_CAR(traj_dim=4, [128, 256, 512, 1024], 500, res_blocks=4)
 FLOP_PER_TRAJ_STEP = 2 * 1_015_085_824  # algorithmic MACs of one TrajUNet forward at L=200
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 
 
-def cpu_baseline(L, T_total, seconds_budget=20.0):
+def cpu_baseline(L, T_total, seconds_budget=20.0, workload="c2"):
     """The oracle (CPU restatement of the reference, stock torch ops) on this host's cores, bounded sample."""
     from _synth import synth_inputs, synth_noise
     from oracle import DiffusionOracle, trajunet_forward
-    from trajectorydiffusion_amd import TrajUNet
+    from trajectorydiffusion_amd import SDUNet_CAR, TrajUNet
     torch.manual_seed(0)
-    sd = {k: v.detach() for k, v in TrajUNet(SCHEDULE, diffusion_steps=T_total, res_blocks=2).state_dict().items()}
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     B = 16
-    x, _, cat, num = synth_inputs(B, L, T_total, seed=0)
+    if workload == "c5":   # the denoiser steps only (the codec runs once per 500 of them)
+        from oracle import latent_oracle
+        sd = {k: v.detach() for k, v in SDUNet_CAR(4, SD_SCHEDULE, T_total, res_blocks=4).state_dict().items()}
+        _, _, cat, num = synth_inputs(B, 8, T_total, seed=0)
+        x = torch.randn((B, 4, L // 8), generator=torch.Generator().manual_seed(0))
+        fwd = lambda x, tv: latent_oracle.sdunet_car_forward(sd, x, tv, cat, num, SD_SCHEDULE, T_total, 4)  # noqa: E731
+    else:
+        sd = {k: v.detach() for k, v in TrajUNet(SCHEDULE, diffusion_steps=T_total, res_blocks=2).state_dict().items()}
+        x, _, cat, num = synth_inputs(B, L, T_total, seed=0)
+        fwd = lambda x, tv: trajunet_forward(sd, x, tv, cat, num, SCHEDULE, T_total)  # noqa: E731
     o = DiffusionOracle(1e-4, 0.05, T_total)
     steps, t0 = 0, time.perf_counter()
     with torch.no_grad():
         for t in range(T_total - 1, -1, -1):
             tv = torch.full((B,), t, dtype=torch.long)
-            eps = trajunet_forward(sd, x, tv, cat, num, SCHEDULE, T_total)
+            eps = fwd(x, tv)
             x = o.posterior_step(x, t, eps, synth_noise(t, x.shape) if t > 0 else None)
             steps += 1
             if time.perf_counter() - t0 > seconds_budget and steps >= 3:
@@ -76,32 +86,49 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
     ap.add_argument("--T", type=int, default=500)
-    ap.add_argument("--L", type=int, default=200)
+    ap.add_argument("--L", type=int, default=None, help="trajectory length (default 200; 199 for --workload c5, eval_sd.ipynb)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"], help="c2 = TrajUNet sampling (the headline); c5 = the latent path: "
+                    "VAE_InvTrans.encode -> q-sample to T-1 -> SDUNet_CAR sampling -> VAE_InvTrans.decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 (reference arithmetic) run of the same config")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--low-latency", action="store_true", help="small-batch serving mode: split-K convs (TrajUNet.set_low_latency)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.L is None:
+        a.L = 199 if a.workload == "c5" else 200
+    return a
 
 
 def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
     """Time `steps` full sampling runs in one compute dtype; returns (elapsed seconds (max over ranks), model, x0)."""
     from _synth import synth_inputs
-    from trajectorydiffusion_amd import DiffusionManager, TrajUNet
+    from trajectorydiffusion_amd import DiffusionManager, SDUNet_CAR, TrajUNet, VAE_InvTrans
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     torch.manual_seed(0)  # same random-init weights on every rank
-    model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype).set_low_latency(a.low_latency)
     dm = DiffusionManager(1e-4, 0.05, a.T, device=str(dev))
     dm.seed = 2024
     B, L = a.batch, a.L
     x_T, _, cat, num = synth_inputs(B, L, a.T, seed=100 + rank)
     x_T, cat, num = x_T.to(dev), cat.to(dev), num.to(dev)
-    gathered = torch.empty((world * B, 2, L), device=dev) if world > 1 else None
+    if a.workload == "c5":
+        model = SDUNet_CAR(4, SD_SCHEDULE, a.T, res_blocks=4).to(dev).eval().set_compute_dtype(dtype)
+        vae = VAE_InvTrans().to(dev).eval()
+        g = torch.Generator().manual_seed(7 + rank)
+        eps0 = torch.randn((B, 4, L // 8), generator=g).to(dev)
+        t_last = torch.full((B,), a.T - 1, dtype=torch.long, device=dev)
+    else:
+        model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype).set_low_latency(a.low_latency)
+    gathered = torch.empty((world * B, 2, L // 8 if a.workload == "c5" else L), device=dev) if world > 1 else None
 
     def one_step():
-        if a.sampler == "ddim":
+        if a.workload == "c5":   # eval_sd.ipynb cells 9-10 (x_T here plays the data trajectories)
+            z0 = vae.encode(x_T)
+            zT = dm.diffusionForward(z0, t_last, eps0)
+            z = dm.diffusionBackward(zT, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
+            x0 = vae.decode(z)
+        elif a.sampler == "ddim":
             x0 = dm.ddimBackward(x_T, cat, num, model, n_steps=a.ddim_steps, use_graph=not a.no_graph)
         else:
             x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
@@ -136,7 +163,7 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
 def conv_roofline(model, a, dtype_name, dev):
     """Roofline of the dominant kernel (conv GEMM): per-launch HIP-event times of one denoise step, on the launch stream."""
     B, L = a.batch, a.L
-    prog = model.program(B, L, dev, split_embed=True)
+    prog = model.program(B, L // 8 if a.workload == "c5" else L, dev, split_embed=True)
     prof = prog.pg.profile(repeats=3)
     gemm = [(n, ms, fl) for n, fn, ms, fl in prof if fn == "tdx_conv_gemm"]
     gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
@@ -156,6 +183,12 @@ def conv_roofline(model, a, dtype_name, dev):
     for n, fn, ms, fl in prof:
         if fn != "tdx_conv_gemm":
             others[fn] = round(others.get(fn, 0.0) + ms, 4)
+    if a.workload == "c5":
+        return {"bound": "mfma", "kernel": "tdx_conv_gemm: every Conv1d / nn.Linear / attention projection of one SDUNet_CAR denoise step (%d calls)" % len(gemm),
+                "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4), "traffic": None,
+                "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm), "flop_per_launch_avg": gemm_fl / len(gemm),
+                "flop_per_traj_step": gemm_fl / B, "gemm_ms_per_step": round(gemm_ms, 3), "other_kernels_ms_per_step": others,
+                "all_kernels_ms_per_step": round(step_ms, 3)}
     return {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call = main grid + optional small-tile tail grid; all %d calls of one denoise step)" % len(gemm),
             "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4),
             "traffic": traffic, "traffic_source": (os.path.relpath(src, ROOT) + " (rocprofv3 --pmc, bytes per launch, avg over the calls of one step)") if traffic is not None else None,
@@ -190,7 +223,21 @@ def main(argv=None):
     elapsed, model = run_leg(a, a.dtype, a.steps, a.warmup, rank, world, dev, dist)
     n_denoise = a.ddim_steps if a.sampler == "ddim" else a.T
     out = None
-    if rank == 0:
+    if rank == 0 and a.workload == "c5":
+        value = world * B * a.steps / elapsed
+        roof = conv_roofline(model, a, a.dtype, dev)
+        out = {
+            "metric": f"trajectories/sec, latent path: VAE_InvTrans.encode + SDUNet_CAR {a.T}-step DDPM sampling + decode, L={L}", "value": round(value, 3),
+            "unit": "trajectories/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"C5: latent path, B={B} per GPU, L={L} (latents (B, 4, {L // 8})), SDUNet_CAR(4, {SD_SCHEDULE}, {a.T}, res_blocks=4) "
+                                   "+ VAE_InvTrans (fp32), random-init weights",
+                       "batch_per_gpu": B, "global_batch": world * B, "diffusion_steps": a.T, "parallelism": f"batch-shard x{world}"},
+            "ms_per_denoise_step": round(1e3 * elapsed / a.steps / n_denoise, 4),
+            "model_tflops": round(value * n_denoise * roof["flop_per_traj_step"] / 1e12 / world, 2),
+            "roofline": roof,
+        }
+    elif rank == 0:
         value = world * B * a.steps / elapsed
         out = {
             "metric": "trajectories/sec, TrajUNet 500-step DDPM sampling L=200" if a.sampler == "ddpm" and a.T == 500 else f"trajectories/sec, TrajUNet {a.sampler} sampling ({n_denoise} denoise steps) L={L}", "value": round(value, 3), "unit": "trajectories/s",
@@ -207,7 +254,7 @@ def main(argv=None):
     torch.cuda.empty_cache()
     # The reference's own arithmetic (fp32: exact f32 MFMA, the 1e-4 parity path) on the same config, in the same run:
     # one warm-up + one timed sampling run (BASELINE.json config 2 names "fp32 + bf16").
-    if a.dtype == "bf16" and not a.no_fp32_leg:
+    if a.dtype == "bf16" and not a.no_fp32_leg and a.workload == "c2":
         el32, m32 = run_leg(a, "fp32", 1, 1, rank, world, dev, dist)
         if rank == 0:
             out["fp32"] = {"value": round(world * B / el32, 3), "unit": "trajectories/s", "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * el32, 3),
@@ -218,7 +265,7 @@ def main(argv=None):
         torch.cuda.empty_cache()
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the other ranks must not idle at the final barrier for it
-            out["cpu_baseline"] = cpu_baseline(L, a.T)
+            out["cpu_baseline"] = cpu_baseline(L, a.T, workload=a.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

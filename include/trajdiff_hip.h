@@ -338,6 +338,46 @@ int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, uint64_t se
 int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int32_t step, void* stream);
 
+/* ---- Latent path: SDUNet_CAR (Models/StableDiffusion.py:114-222) between
+ * VAE_InvTrans.encode / decode (Models/VAE.py:135-192).  Every Conv1d / nn.Linear / attention projection of both models is a
+ * tdx_conv_gemm; the entry points below are the remaining ops.  Rows are channels-last (B, L, C) as everywhere else. ---- */
+
+/* Core of nn.MultiheadAttention(C, 8, batch_first=True)(x, cond, cond) (StableDiffusionBlocks.py:58,77) after the input
+ * projections: q (B, L, C) rows, kv (B, N, 2C) rows [K | V] of the N <= 8 condition tokens (7 in the reference); out (B, L, C) =
+ * per head softmax(q_h K_h^T / sqrt(C / 8)) V_h, heads concatenated (the out_proj GEMM follows).  C in {128, 256, 512, 1024}. */
+int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, int32_t kv_ld, void* out, int32_t out_ld, int32_t B, int32_t L,
+                        int32_t N, int32_t C, int32_t heads, int32_t dtype, void* stream);
+
+/* Core of the self-attention of InvTransformerBlock (VAEBlocks.py:109,120: tokens = channels, embedding = positions), fp32:
+ * qkv (B, T, 3E) [q | k | v] -> out (B, T, E); E / heads <= 16 and T * E <= 8192. */
+int tdx_mha_small(const float* qkv, float* out, int32_t B, int32_t T, int32_t E, int32_t heads, void* stream);
+
+/* Layout: (B, C, L) fp32 channels-first -> rows (B, L, ld) of `dtype` (channels C .. ld-1 zero: padding up to the GEMM's
+ * vector width), and back (VAEBlocks.py:120 switches between the two views of one tensor; the model I/O is channels-first). */
+int tdx_chanfirst_to_rows(const float* x, void* out, int32_t B, int32_t C, int32_t L, int32_t ld, int32_t dtype, void* stream);
+int tdx_rows_to_chanfirst(const void* rows, int32_t ld, float* out, int32_t B, int32_t C, int32_t L, int32_t dtype, void* stream);
+
+/* Resampling along the trajectory on rows (B, lin, C) -> (B, lout, C):
+ *   mode 0  nn.Upsample(mode='nearest') (StableDiffusion.py:166): src = min(floor(dst * (float)lin / lout), lin - 1);
+ *   mode 1  nn.Upsample(mode='linear', align_corners=True) (VAE.py:142,156,160): src = dst * (lin - 1) / (lout - 1);
+ *   mode 2  F.adaptive_avg_pool1d (VAE.py:181,192): mean over [floor(i lin / lout), ceil((i + 1) lin / lout)). */
+int tdx_resample_rows(const void* x, void* out, int32_t B, int32_t lin, int32_t lout, int32_t C, int32_t mode, int32_t dtype, void* stream);
+
+/* ConditionMixBlock's gathers (StableDiffusionBlocks.py:132-138), fp32, hidden width H: pe (B, H) = pos_enc[time];
+ * catvec (B, 5H) = [cell_emb[cat 0..3] | day_emb[cat 4]]; mix_in (B, 7H) columns 6H.. = LeakyReLU(numerical_fc(num)) (the other
+ * columns are written by the time / categorical GEMMs, each applying mix_fc's leading LeakyReLU to its own slice).
+ * err_flag bits as tdx_embed_gather (1: time out of range, 2: categorical index out of range). */
+int tdx_condmix_gather(const int64_t* time, const int64_t* cat, const float* num, const float* pos_enc, int32_t max_time,
+                       const float* cell_emb, const float* day_emb, const float* num_w, const float* num_b, float* pe, float* catvec,
+                       float* mix_in, int32_t hidden, int32_t B, int32_t* err_flag, void* stream);
+
+/* Stem Conv1d(cin -> C0, 3, 1, 1), cin <= 8, from x (B, cin, L) fp32 to rows (B, L, C0) (StableDiffusion.py:127), and head
+ * Conv1d(C0 -> cout, 3, 1, 1), cout <= 8, from rows to (B, cout, L) fp32 (:150); w in the reference layout, fp32. */
+int tdx_stem_conv_n(const float* x, const float* w, const float* bias, void* out, int32_t B, int32_t L, int32_t cin, int32_t C0,
+                    int32_t dtype, void* stream);
+int tdx_head_conv_n(const void* a, const float* w, const float* bias, float* out, int32_t B, int32_t L, int32_t C0, int32_t cout,
+                    int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

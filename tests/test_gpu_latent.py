@@ -1,0 +1,312 @@
+"""GPU: the latent path (SDUNet_CAR between VAE_InvTrans.encode / decode, config C5) through the C ABI against
+oracle/latent_oracle.py.  PARITY UNPINNED: the reference holds no golden vector for these models and may not be executed
+here, so the oracle these tests compare against is a restatement by reading (see its header)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import latent_oracle as O  # noqa: E402
+
+FP32_TOL = 1e-4   # relative = max |err| / max |ref| over the tensor, as for TrajUNet
+BF16_TOL = 2e-2   # 25 blocks of bf16 GEMMs feeding GroupNorms (TrajUNet: 17 blocks, 1e-2)
+FULL = [128, 256, 512, 1024]
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def randomise(m, seed):
+    """Default initialisation leaves biases / GroupNorm affine / BatchNorm statistics at trivial values: perturb everything."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 1 else 0.01))
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.2)
+            elif n.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    return m
+
+
+def inputs(B, D, L, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, D, L), generator=g)
+    t = torch.randint(0, T, (B,), generator=g)
+    cat = torch.cat([torch.randint(0, 256, (B, 4), generator=g), torch.randint(0, 33, (B, 1), generator=g)], dim=1)
+    num = torch.randn((B, 3), generator=g)
+    return x, t, cat, num
+
+
+def cpu_sd(m):
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+# ---- kernels ----------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("C", [128, 256, 512, 1024])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_attention_core(C, dtype):
+    from trajectorydiffusion_amd import _lib
+    B, L, N, H = 5, 7, 7, 8
+    g = torch.Generator().manual_seed(C)
+    q = torch.randn((B, L, C), generator=g).to(dtype)
+    kv = torch.randn((B, N, 2 * C), generator=g).to(dtype)
+    qd, kvd = q.cuda(), kv.cuda()
+    out = torch.empty_like(qd)
+    _lib.check(_lib.lib().tdx_cross_attention(qd.data_ptr(), C, kvd.data_ptr(), 2 * C, out.data_ptr(), C, B, L, N, C, H, _lib.dtype_code(dtype),
+                                              _lib.stream_ptr()), "tdx_cross_attention")
+    qf, kf, vf = q.double(), kv[..., :C].double(), kv[..., C:].double()
+    hd = C // H
+    qh = qf.view(B, L, H, hd).transpose(1, 2)
+    kh = kf.view(B, N, H, hd).transpose(1, 2)
+    vh = vf.view(B, N, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, L, C)
+    assert rel(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+def test_cross_attention_rejects_unsupported_shapes():
+    from trajectorydiffusion_amd import _lib
+    t = torch.zeros(4096, device="cuda")
+    lib = _lib.lib()
+    assert lib.tdx_cross_attention(t.data_ptr(), 64, t.data_ptr(), 128, t.data_ptr(), 64, 1, 1, 7, 64, 8, 0, _lib.stream_ptr()) != 0   # C = 64
+    assert lib.tdx_cross_attention(t.data_ptr(), 128, t.data_ptr(), 256, t.data_ptr(), 128, 1, 1, 9, 128, 8, 0, _lib.stream_ptr()) != 0  # 9 tokens
+    assert lib.tdx_cross_attention(t.data_ptr(), 128, t.data_ptr(), 256, t.data_ptr(), 128, 1, 1, 7, 128, 4, 0, _lib.stream_ptr()) != 0  # 4 heads
+    assert b"tdx_cross_attention" in lib.tdx_last_error()
+
+
+@pytest.mark.parametrize("T,E", [(32, 128), (64, 64), (128, 32)])
+def test_mha_small_core(T, E):
+    from trajectorydiffusion_amd import _lib
+    B, H = 3, 8
+    qkv = torch.randn((B, T, 3 * E), generator=torch.Generator().manual_seed(T))
+    qd = qkv.cuda()
+    out = torch.empty((B, T, E), device="cuda")
+    _lib.check(_lib.lib().tdx_mha_small(qd.data_ptr(), out.data_ptr(), B, T, E, H, _lib.stream_ptr()), "tdx_mha_small")
+    hd = E // H
+    q, k, v = (qkv[..., i * E:(i + 1) * E].double().view(B, T, H, hd).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1) @ v).transpose(1, 2).reshape(B, T, E)
+    assert rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("lin,lout,mode", [(199, 256, 1), (24, 32, 1), (32, 64, 1), (3, 6, 0), (12, 24, 0), (32, 24, 2), (256, 24, 2), (32, 3, 2),
+                                           (5, 5, 1), (7, 1, 2)])
+def test_resample_rows_matches_aten(lin, lout, mode):
+    from trajectorydiffusion_amd import _lib
+    B, C = 3, 8
+    x = torch.randn((B, C, lin), generator=torch.Generator().manual_seed(lin * 7 + lout))
+    if mode == 0:
+        ref = F.interpolate(x, size=lout, mode="nearest")
+    elif mode == 1:
+        ref = F.interpolate(x, size=lout, mode="linear", align_corners=True)
+    else:
+        ref = F.adaptive_avg_pool1d(x, lout)
+    rows = x.permute(0, 2, 1).contiguous().cuda()
+    out = torch.empty((B, lout, C), device="cuda")
+    _lib.check(_lib.lib().tdx_resample_rows(rows.data_ptr(), out.data_ptr(), B, lin, lout, C, mode, 0, _lib.stream_ptr()), "tdx_resample_rows")
+    got = out.cpu().permute(0, 2, 1)
+    if mode == 0:
+        assert torch.equal(got, ref)
+    else:
+        assert float((got - ref).abs().max()) < 2e-6
+
+
+def test_layout_round_trip_and_padding():
+    from trajectorydiffusion_amd import _lib
+    lib = _lib.lib()
+    B, C, L, ld = 3, 2, 11, 4
+    x = torch.randn((B, C, L), device="cuda")
+    for dtype in (torch.float32, torch.bfloat16):
+        rows = torch.full((B, L, ld), 7.0, device="cuda", dtype=dtype)
+        _lib.check(lib.tdx_chanfirst_to_rows(x.data_ptr(), rows.data_ptr(), B, C, L, ld, _lib.dtype_code(dtype), _lib.stream_ptr()), "to_rows")
+        assert torch.equal(rows[..., :C], x.permute(0, 2, 1).to(dtype))
+        assert float(rows[..., C:].abs().max()) == 0.0
+        back = torch.empty((B, C, L), device="cuda")
+        _lib.check(lib.tdx_rows_to_chanfirst(rows.data_ptr(), ld, back.data_ptr(), B, C, L, _lib.dtype_code(dtype), _lib.stream_ptr()), "to_chanfirst")
+        assert torch.equal(back, x.to(dtype).float())
+
+
+def test_condition_mix_block_matches_oracle():
+    from trajectorydiffusion_amd import ConditionMixBlock
+    m = randomise(ConditionMixBlock(50, hidden_dim=128, embed_dim=128), 1).eval()
+    sd = {"embed_block." + k: v for k, v in cpu_sd(m).items()}
+    _, t, cat, num = inputs(9, 4, 8, 50, 2)
+    ref = O.condition_mix(sd, t, cat, num, 50)
+    got = m.cuda()(t.cuda(), cat.cuda(), num.cuda())
+    assert got.shape == (9, 896)
+    assert rel(got, ref) < 1e-5
+    bad = cat.clone()
+    bad[0, 4] = 33
+    with pytest.raises(IndexError):
+        m(t.cuda(), bad.cuda(), num.cuda())
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 256), (512, 256)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_attention_res_matches_oracle(cin, cout, dtype):
+    from trajectorydiffusion_amd import CrossAttentionRes
+    m = randomise(CrossAttentionRes(cin, cout, 8), cin + cout).eval()
+    sd = cpu_sd(m)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((3, cin, 6), generator=g)
+    cond = torch.randn((3, 896), generator=g)
+    ref = O.cross_attention_res(sd, "", x, cond)
+    m.cuda().set_compute_dtype(dtype)
+    got = m(x.cuda(), cond.cuda())
+    assert rel(got, ref) < (FP32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+# ---- whole models --------------------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def car():
+    from trajectorydiffusion_amd import SDUNet_CAR
+    torch.manual_seed(11)
+    return randomise(SDUNet_CAR(4, FULL, 500, res_blocks=4), 3).eval()   # the eval_sd.ipynb configuration, 162.7 M parameters
+
+
+@pytest.fixture(scope="module")
+def car_sd(car):
+    return cpu_sd(car)
+
+
+def test_sdunet_car_matches_survey_parameter_count(car):
+    assert sum(p.numel() for p in car.parameters()) == 162_682_884   # "162.7 M params"
+
+
+def test_sdunet_car_forward_fp32_b4(car, car_sd):
+    x, t, cat, num = inputs(4, 4, 24, 500, 21)
+    ref = O.sdunet_car_forward(car_sd, x, t, cat, num, FULL, 500, 4)
+    car.cuda().set_compute_dtype(torch.float32)
+    got = car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+    assert got.shape == (4, 4, 24)
+    assert rel(got, ref) < FP32_TOL
+
+
+def test_sdunet_car_forward_bf16_b4(car, car_sd):
+    x, t, cat, num = inputs(4, 4, 24, 500, 22)
+    ref = O.sdunet_car_forward(car_sd, x, t, cat, num, FULL, 500, 4)
+    car.cuda().set_compute_dtype(torch.bfloat16)
+    got = car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+    assert rel(got, ref) < BF16_TOL
+    car.set_compute_dtype(torch.float32)
+
+
+def test_sdunet_car_other_lengths_and_rejects_odd(car, car_sd):
+    from trajectorydiffusion_amd._lib import TdxError
+    car.cuda().set_compute_dtype(torch.float32)
+    x, t, cat, num = inputs(2, 4, 8, 500, 23)   # the shortest length three halvings allow: the mid block runs at L = 1
+    ref = O.sdunet_car_forward(car_sd, x, t, cat, num, FULL, 500, 4)
+    assert rel(car(x.cuda(), t.cuda(), cat.cuda(), num.cuda()), ref) < FP32_TOL
+    x, t, cat, num = inputs(2, 4, 20, 500, 24)  # 20 -> 10 -> 5 -> odd: the reference's decoder concat fails there too
+    with pytest.raises(TdxError):
+        car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+
+
+@pytest.fixture(scope="module")
+def vae():
+    from trajectorydiffusion_amd import VAE_InvTrans
+    torch.manual_seed(12)
+    return randomise(VAE_InvTrans(), 4).eval()
+
+
+def test_vae_encode_decode_match_oracle(vae):
+    sd = cpu_sd(vae)
+    x = torch.randn((4, 2, 199), generator=torch.Generator().manual_seed(31))
+    z_ref = O.vae_encode(sd, x)
+    vae.cuda()
+    z = vae.encode(x.cuda())
+    assert z.shape == (4, 4, 24)
+    assert rel(z, z_ref) < FP32_TOL
+    y_ref = O.vae_decode(sd, z_ref)
+    y = vae.decode(z_ref.cuda())
+    assert y.shape == (4, 2, 24)          # the reference's decode pools to the LATENT length (VAE.py:191-192)
+    assert rel(y, y_ref) < FP32_TOL
+    x2 = torch.randn((3, 2, 64), generator=torch.Generator().manual_seed(32))   # another batch / length: L // 8 = 8
+    assert rel(vae.encode(x2.cuda()), O.vae_encode(sd, x2)) < FP32_TOL
+
+
+def test_vae_sees_batchnorm_statistic_updates(vae):
+    vae.cuda()
+    x = torch.randn((2, 2, 40), generator=torch.Generator().manual_seed(33)).cuda()
+    before = vae.encode(x)
+    with torch.no_grad():
+        vae.encoder[1][1].running_mean.add_(0.5)
+    after = vae.encode(x)
+    assert rel(after, O.vae_encode(cpu_sd(vae), x.cpu())) < FP32_TOL
+    assert float((after - before).abs().max()) > 1e-4
+    with torch.no_grad():
+        vae.encoder[1][1].running_mean.sub_(0.5)
+
+
+def test_latent_pipeline_b4_injected_noise(car, car_sd, vae):
+    """eval_sd.ipynb cells 9-10: encode, T-step DDPM sampling in latent space, decode; the same z injected on both sides."""
+    from oracle import DiffusionOracle
+    from trajectorydiffusion_amd import DiffusionManager
+    T = 6
+    vsd = cpu_sd(vae)
+    g = torch.Generator().manual_seed(41)
+    traj = torch.randn((4, 2, 199), generator=g)
+    _, _, cat, num = inputs(4, 4, 24, 500, 42)
+    noise = torch.randn((T, 4, 4, 24), generator=g)
+    eps = torch.randn((4, 4, 24), generator=g)
+    # oracle side
+    do = DiffusionOracle(0.0001, 0.05, T)
+    z0 = O.vae_encode(vsd, traj)
+    tt = torch.full((4,), T - 1, dtype=torch.long)
+    zT = do.q_sample(z0, tt, eps)
+    model_fn = lambda x, t: O.sdunet_car_forward(car_sd, x, t, cat, num, FULL, 500, 4)   # noqa: E731
+    z_rec = do.sample(zT, model_fn, lambda t: noise[t])
+    ref = O.vae_decode(vsd, z_rec)
+    # product side
+    car.cuda().set_compute_dtype(torch.float32)
+    vae.cuda()
+    dm = DiffusionManager(0.0001, 0.05, T, device="cuda")
+    z0d = vae.encode(traj.cuda())
+    zTd = dm.diffusionForward(z0d, tt.cuda(), eps.cuda())
+    for use_graph in (True, False):
+        z_recd = dm.diffusionBackward(zTd, cat.cuda(), num.cuda(), car, noise=noise.cuda(), use_graph=use_graph)
+        got = vae.decode(z_recd)
+        assert rel(z_recd, z_rec) < 5e-4
+        assert rel(got, ref) < 5e-4
+
+
+def test_latent_sampling_seeded_philox_is_reproducible_and_shardable(car):
+    from trajectorydiffusion_amd import DiffusionManager
+    car.cuda().set_compute_dtype(torch.bfloat16)
+    dm = DiffusionManager(0.0001, 0.05, 4, device="cuda")
+    dm.seed = 1234
+    x, _, cat, num = inputs(8, 4, 24, 500, 51)
+    a = dm.diffusionBackward(x.cuda(), cat.cuda(), num.cuda(), car)
+    b = dm.diffusionBackward(x.cuda(), cat.cuda(), num.cuda(), car)
+    assert torch.equal(a, b)
+    lo = dm.diffusionBackward(x[:4].cuda(), cat[:4].cuda(), num[:4].cuda(), car)
+    hi = dm.diffusionBackward(x[4:].cuda(), cat[4:].cuda(), num[4:].cuda(), car, first_sample=4)
+    # shards draw the noise of their global sample indices; the GEMM tiling may differ with the batch size, so compare to bf16 accuracy
+    assert rel(torch.cat([lo, hi]), a) < BF16_TOL
+    assert torch.isfinite(a).all()
+    car.set_compute_dtype(torch.float32)
+
+
+def test_c5_full_size_b4096_properties(car, car_sd):
+    """B = 4096 (BASELINE.json C5), bf16: finite; trajectories are independent (a batch permutation permutes the output; the rows of
+    a half-batch run match); a handful of rows against the oracle."""
+    car.cuda().set_compute_dtype(torch.bfloat16)
+    B = 4096
+    x, t, cat, num = inputs(B, 4, 24, 500, 61)
+    xd, td, cd, nd = x.cuda(), t.cuda(), cat.cuda(), num.cuda()
+    full = car(xd, td, cd, nd)
+    assert full.shape == (B, 4, 24) and torch.isfinite(full).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(62)).cuda()
+    assert torch.equal(car(xd[perm], td[perm], cd[perm], nd[perm]), full[perm])
+    half = car(xd[:2048], td[:2048], cd[:2048], nd[:2048])
+    assert rel(half, full[:2048]) < 1e-6 or torch.equal(half, full[:2048])
+    idx = [0, 1, 2047, 4095]
+    ref = O.sdunet_car_forward(car_sd, x[idx], t[idx], cat[idx], num[idx], FULL, 500, 4)
+    assert rel(full[idx], ref) < BF16_TOL
+    car.set_compute_dtype(torch.float32)
+    car._programs.clear()

@@ -116,14 +116,15 @@ class DiffusionManager:
         """T-step DDPM sampling.  Extensions over the reference signature (all optional):
         noise        injected z: tensor (max_t, B, C, L) indexed by t, or callable t -> (B, C, L); default in-kernel Philox
         first_sample global index of sample 0 (batch shards draw the same noise as the unsharded batch)
-        use_graph    capture one denoise step into a HIP graph and replay it (TrajUNet models only)
+        use_graph    capture one denoise step into a HIP graph and replay it (this package's TrajUNet / SDUNet_CAR)
         """
         if max_t is None:
             max_t = self.T
         if not 0 < max_t <= self.T:
             raise IndexError(f"diffusionBackward: max_t={max_t} out of (0, {self.T}]")
+        from .Models.StableDiffusion import SDUNet_CAR
         from .Models.TrajUNet import TrajUNet
-        if isinstance(model, TrajUNet):
+        if isinstance(model, (TrajUNet, SDUNet_CAR)):
             from .sampler import GraphSampler
             key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, max_t, "ddpm", getattr(model, "low_latency", False))
             smp = self._samplers.get(key)
@@ -147,10 +148,11 @@ class DiffusionManager:
     @torch.no_grad()
     def ddimBackward(self, x_T: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor, model: torch.nn.Module,
                      n_steps: int = 50, use_graph: bool = True) -> torch.Tensor:
+        from .Models.StableDiffusion import SDUNet_CAR
         from .Models.TrajUNet import TrajUNet
         from .sampler import GraphSampler
-        if not isinstance(model, TrajUNet):
-            raise TdxError("ddimBackward: only this package's TrajUNet is supported")
+        if not isinstance(model, (TrajUNet, SDUNet_CAR)):
+            raise TdxError("ddimBackward: only this package's TrajUNet / SDUNet_CAR are supported")
         key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, n_steps, "ddim", getattr(model, "low_latency", False))
         smp = self._samplers.get(key)
         if smp is None or not smp.valid():

@@ -12,7 +12,8 @@ import torch.nn as nn
 
 from .. import _lib, engine
 from .._lib import ACT_NONE, TdxError
-from .TrajUNetBlocks import AttnBlock, ResnetBlock, WideAndDeepEmbedBlock, _HipBlock
+from ._packed import _PackedModel
+from .TrajUNetBlocks import AttnBlock, ResnetBlock, WideAndDeepEmbedBlock
 
 
 class UNetProgram:
@@ -196,7 +197,7 @@ class UNetProgram:
         self.pg.run()
 
 
-class TrajUNet(_HipBlock):
+class TrajUNet(_PackedModel):
     def __init__(self, channel_schedule: List[int], traj_length: int = 200, diffusion_steps: int = 300, res_blocks: int = 2) -> None:
         super().__init__()
         if res_blocks < 2:
@@ -231,10 +232,7 @@ class TrajUNet(_HipBlock):
             self.embed_offsets[key] = off
             off += blk.out_c
         self.embed_cols = off
-        self._packed: Dict[torch.dtype, Tuple] = {}   # dtype -> (version sum, parameter addresses, norm digest, tensors)
-        self.weights_epoch = 0                          # bumped by every (re)pack: samplers re-derive their time-step tables
-        self._programs: Dict[Tuple, UNetProgram] = {}
-        self.low_latency = False
+        self._init_cache()   # packed weights, programs, weights_epoch, low_latency (Models/_packed.py)
 
     def set_low_latency(self, on: bool = True) -> "TrajUNet":
         """Small-batch serving mode (no reference counterpart): convs with too few output tiles to fill the 256 CUs are cut
@@ -254,29 +252,6 @@ class TrajUNet(_HipBlock):
             for j in range(self.res_blocks - 1):
                 yield f"up_blocks.{i}.{j}.", self.up_blocks[i][j]
 
-    def _fingerprint(self) -> Tuple[int, Tuple[int, ...]]:
-        """(sum of the parameters' autograd versions, their storage addresses).  In-place updates through the parameter
-        (optimizers, load_state_dict, copy_ under no_grad) bump a version; p.data = t / load_state_dict(assign=True) / .to()
-        change an address.  Writes through `.data` (param.data.copy_(...), the reference's Utils.EMA.getModel, Utils.py:107) change
-        NEITHER: the sampler detects them with _data_digest(); for a bare eval forward() call invalidate() after such a write."""
-        ps = list(self.parameters())
-        return sum(p._version for p in ps), tuple(p.data_ptr() for p in ps)
-
-    def _data_digest(self) -> Optional[torch.Tensor]:
-        """Per-parameter L2 norms on the device (236 floats): compared against the norms the cached GEMM-layout copies were
-        built from, this catches weight updates that no version counter sees.  One pass over 190 MB, no host sync of its own."""
-        ps = [p.detach() for p in self.parameters()]
-        if not ps or not all(p.is_cuda for p in ps):
-            return None
-        return torch.stack(torch._foreach_norm(ps))
-
-    def invalidate(self) -> "TrajUNet":
-        """Force the cached GEMM-layout weight copies to be refreshed before the next forward / sampling call.  Needed only
-        after writing weights through `.data` before a bare eval-mode forward(); everything else is detected."""
-        for dt, hit in list(self._packed.items()):
-            self._packed[dt] = (-1,) + tuple(hit[1:])
-        return self
-
     def _build_packed(self, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
         out: Dict[str, torch.Tensor] = {}
         with torch.no_grad():
@@ -293,34 +268,6 @@ class TrajUNet(_HipBlock):
             out["embed_proj.b"] = torch.cat([blk.embed_proj.bias.detach() for _, blk in self.executed_resblocks()]).float().contiguous()
         return out
 
-    def packed_weights(self, dtype: torch.dtype, check_data: bool = False) -> Dict[str, torch.Tensor]:
-        """GEMM-layout weights in the compute dtype, refreshed whenever a parameter changes.  A refresh writes INTO the cached
-        tensors, so programs and captured graphs (which hold their addresses) stay valid; only when a parameter's storage
-        moved are the programs (which also hold raw parameter pointers: biases, GroupNorm affine, stem/head) dropped.
-        check_data: also compare the parameters' norms with those at packing time (writes through `.data`)."""
-        ver, ptrs = self._fingerprint()
-        hit = self._packed.get(dtype)
-        if hit is not None and hit[1] != ptrs:
-            self._packed.clear()
-            self._programs.clear()
-            hit = None
-        digest = None
-        stale = hit is None or hit[0] != ver
-        if not stale and check_data:
-            digest = self._data_digest()
-            stale = digest is not None and (hit[2] is None or not torch.equal(digest, hit[2]))
-        if not stale:
-            return hit[3]
-        new = self._build_packed(dtype)
-        if hit is not None:
-            with torch.no_grad():
-                for k, v in new.items():
-                    hit[3][k].copy_(v)
-            new = hit[3]
-        self._packed[dtype] = (ver, ptrs, self._data_digest() if digest is None else digest, new)
-        self.weights_epoch += 1
-        return new
-
     def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> UNetProgram:
         dtype = self.compute_dtype if dtype is None else dtype
         self.packed_weights(dtype)  # refresh (drops stale programs) before the cache lookup
@@ -330,13 +277,6 @@ class TrajUNet(_HipBlock):
             prog = UNetProgram(self, B, L, dtype, device, split_embed)
             self._programs[key] = prog
         return prog
-
-    def _apply(self, fn, *a, **k):
-        super()._apply(fn, *a, **k)
-        self._packed.clear()
-        self._programs.clear()
-        self.__dict__.pop("_train_steps", None)   # TrainStep programs hold views of the old parameter storage
-        return self
 
     def time_bias_table(self, t_values: torch.Tensor) -> torch.Tensor:
         """(len(t_values), embed_cols) fp32 rows W_e[:, :128] . swish(time_embed(t)) for the sampler's step table."""

@@ -1,4 +1,4 @@
-"""Graph-captured sampling loop for TrajUNet (the loop of reference DiffusionManager.py:66-79).
+"""Graph-captured sampling loop for TrajUNet and SDUNet_CAR (the loop of reference DiffusionManager.py:66-79).
 
 One denoise step = {step bookkeeping, the UNet program, the fused posterior update} is captured
 ONCE into a HIP graph; the step index lives in device memory (tdx_step_prepare advances it), so the
@@ -37,11 +37,12 @@ class GraphSampler:
         self.nsteps = len(ts)
         self.coef_table = coef.to(torch.float32).contiguous().to(device)
         self.step_to_t = ts.to(torch.int32).to(device)
-        self.tbias_table = model.time_bias_table(ts.to(device))
+        self.D = self.prog.x.shape[1]                                 # trajectory channels: 2 (TrajUNet) or 4 (latents)
+        self.tbias_table = model.time_bias_table(ts.to(device))       # None: the model has no per-step time-bias row (SDUNet_CAR)
         self._epoch = model.weights_epoch
         self.coef_cur = torch.zeros(4, dtype=torch.float32, device=device)
         self.ctr = torch.zeros(4, dtype=torch.int32, device=device)  # {step, seed_lo, seed_hi, -}
-        self.zbuf = torch.zeros((B, 2, L), dtype=torch.float32, device=device)
+        self.zbuf = torch.zeros((B, self.D, L), dtype=torch.float32, device=device)
         self.graphs = {}
         self.first_elem = 0
 
@@ -53,14 +54,15 @@ class GraphSampler:
         if self.model._programs.get(self._prog_key) is not self.prog:
             return False
         if self.model.weights_epoch != self._epoch:
-            self.tbias_table.copy_(self.model.time_bias_table(self.ts.to(self.device)))
+            if self.tbias_table is not None:
+                self.tbias_table.copy_(self.model.time_bias_table(self.ts.to(self.device)))
             self._epoch = self.model.weights_epoch
         return True
 
     def _step(self, inject: bool) -> None:
         p, st = self.prog, _lib.stream_ptr()
         _lib.check(self.lib.tdx_step_prepare(self.ctr.data_ptr(), self.coef_table.data_ptr(), 4, self.coef_cur.data_ptr(),
-                                             self.tbias_table.data_ptr(), self.model.embed_cols, p.tbias.data_ptr(),
+                                             _lib.ptr(self.tbias_table), self.model.embed_cols, _lib.ptr(p.tbias),
                                              self.step_to_t.data_ptr(), p.time.data_ptr(), self.B, self.nsteps, st), "tdx_step_prepare")
         p.run()
         n = p.x.numel()
@@ -91,18 +93,19 @@ class GraphSampler:
         p = self.prog
         for t, name in ((x_T, "x_T"), (cat_attr, "cat_attr"), (num_attr, "num_attr")):
             _lib.require_device(t, name)
-        if tuple(x_T.shape) != (self.B, 2, self.L):
-            raise TdxError(f"sampler built for {(self.B, 2, self.L)}, got x_T {tuple(x_T.shape)}")
+        if tuple(x_T.shape) != (self.B, self.D, self.L):
+            raise TdxError(f"sampler built for {(self.B, self.D, self.L)}, got x_T {tuple(x_T.shape)}")
         inject = noise is not None and not self.ddim
-        self.first_elem = int(first_sample) * 2 * self.L
+        self.first_elem = int(first_sample) * self.D * self.L
         if self.first_elem % 4:
-            raise TdxError("first_sample * 2 * L must be a multiple of 4")
-        graph = self._graph(inject) if use_graph else None  # (its warm-up step scribbles on x / ctr: load inputs after)
-        p.x.copy_(x_T)
-        p.cat.copy_(cat_attr)
+            raise TdxError("first_sample * channels * L must be a multiple of 4")
+        p.cat.copy_(cat_attr)   # (before the capture: a model that gathers its attributes inside the step must not see stale indices)
         p.num.copy_(num_attr)
         p.time.zero_()
-        p.embed_pg.run()  # attribute half of every embed_proj, once per call
+        graph = self._graph(inject) if use_graph else None  # (its warm-up step scribbles on x / ctr: load x after)
+        p.x.copy_(x_T)
+        if p.embed_pg is not None:
+            p.embed_pg.run()  # attribute half of every embed_proj, once per call
         engine.check_err_flag(p.err, "diffusionBackward")
         seed = self.dm._draw_seed()
         self.ctr.copy_(torch.tensor(self.dm.seed_words(seed), dtype=torch.int32))
@@ -118,4 +121,6 @@ class GraphSampler:
                 self._step(inject)
             if trace is not None:
                 trace.append((t, x_before, p.eps.clone()))
+        if p.embed_pg is None:   # attribute gathers ran inside the steps: report their range errors now
+            engine.check_err_flag(p.err, "diffusionBackward")
         return p.x.clone()

@@ -343,10 +343,11 @@ int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * tdx_conv_gemm; the entry points below are the remaining ops.  Rows are channels-last (B, L, C) as everywhere else. ---- */
 
 /* Core of nn.MultiheadAttention(C, 8, batch_first=True)(x, cond, cond) (StableDiffusionBlocks.py:58,77) after the input
- * projections: q (B, L, C) rows, kv (B, N, 2C) rows [K | V] of the N <= 8 condition tokens (7 in the reference); out (B, L, C) =
- * per head softmax(q_h K_h^T / sqrt(C / 8)) V_h, heads concatenated (the out_proj GEMM follows).  C in {128, 256, 512, 1024}. */
-int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, int32_t kv_ld, void* out, int32_t out_ld, int32_t B, int32_t L,
-                        int32_t N, int32_t C, int32_t heads, int32_t dtype, void* stream);
+ * projections: q (B, L, C) rows; K | V rows of the N <= 8 condition tokens (7 in the reference): token n of trajectory b at
+ * kv + b * kv_bs + n * kv_ld (elements), 2C wide [K | V]; out (B, L, C) = per head softmax(q_h K_h^T / sqrt(C / 8)) V_h, heads
+ * concatenated (the out_proj GEMM follows).  C in {128, 256, 512, 1024}; pitches and pointers 16-byte aligned. */
+int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, int32_t kv_ld, int64_t kv_bs, void* out, int32_t out_ld, int32_t B,
+                        int32_t L, int32_t N, int32_t C, int32_t heads, int32_t dtype, void* stream);
 
 /* Core of the self-attention of InvTransformerBlock (VAEBlocks.py:109,120: tokens = channels, embedding = positions), fp32:
  * qkv (B, T, 3E) [q | k | v] -> out (B, T, E); E / heads <= 16 and T * E <= 8192. */

@@ -57,6 +57,10 @@ class SDProgram:
         else:
             cond = pg.alloc((B, E))
             pg.call("cond.cast", pg.lib.tdx_chanfirst_to_rows, cond32.data_ptr(), cond.data_ptr(), B, E, 1, E, pg.code, keep=[cond32, cond])
+        # K | V rows of the 7 condition tokens for all blocks at once: one (B x 896) x (896 x 14 sum C) GEMM per denoise step
+        kvm = pg.alloc((B, m.kv_cols))
+        pg.conv([Seg(cond, E, E, 1, taps=1)], packed["kv_all.w"], packed["kv_all.b"], kvm, m.kv_cols, B, 1, m.kv_cols, name="kv_all")
+        kv = lambda key: (kvm, m.kv_offsets[key])  # noqa: E731
         cur = pg.alloc((B, L, cs[0]))
         pg.call("stem", pg.lib.tdx_stem_conv_n, self.x.data_ptr(), fp32_param(m.stem.weight, "stem.weight").data_ptr(),
                 fp32_param(m.stem.bias, "stem.bias").data_ptr(), cur.data_ptr(), B, L, m.traj_dim, cs[0], pg.code, keep=[cur])
@@ -67,7 +71,7 @@ class SDProgram:
             for j in range(R):
                 key = f"down_blocks.{i}.{j}."
                 blk = m.down_blocks[i][j]
-                nxt = blk.emit(pg, packed, key, [(cur, blk.in_c)], cond, B, li)
+                nxt = blk.emit(pg, packed, key, [(cur, blk.in_c)], None, B, li, kv_all=kv(key))
                 if not cur_is_skip:
                     pg.release(cur)
                 cur, cur_is_skip = nxt, False
@@ -78,7 +82,7 @@ class SDProgram:
             pg.release(cur)
             downs.append(d)
             cur, cur_is_skip = d, True
-        cur = m.mid_attn_block.emit(pg, packed, "mid_attn_block.", [(downs[-1], cs[-1])], cond, B, lens[-1])   # :220 (downs[-1] stays live: skip)
+        cur = m.mid_attn_block.emit(pg, packed, "mid_attn_block.", [(downs[-1], cs[-1])], None, B, lens[-1], kv_all=kv("mid_attn_block."))   # :220 (downs[-1] stays live: skip)
         for i in range(S):   # decoder, :198-205
             skip = downs[-i - 1]
             li, lo = lens[S - i], lens[S - i - 1]
@@ -86,7 +90,7 @@ class SDProgram:
             srcs: List[Tuple[torch.Tensor, int]] = [(cur, cskip), (skip, cskip)]
             for j in range(R - 1):
                 key = f"up_blocks.{i}.{j}."
-                nxt = m.up_blocks[i][j].emit(pg, packed, key, srcs, cond, B, li)
+                nxt = m.up_blocks[i][j].emit(pg, packed, key, srcs, None, B, li, kv_all=kv(key))
                 for t, _ in srcs:
                     pg.release(t)
                 srcs = [(nxt, co)]
@@ -95,7 +99,7 @@ class SDProgram:
             pg.call(f"up_blocks.{i}.upsample", pg.lib.tdx_resample_rows, cur.data_ptr(), up.data_ptr(), B, li, lo, co, 0, pg.code, keep=[cur, up])
             pg.release(cur)
             key = f"up_blocks.{i}.{R}."
-            cur = m.up_blocks[i][R].emit(pg, packed, key, [(up, co)], cond, B, lo)
+            cur = m.up_blocks[i][R].emit(pg, packed, key, [(up, co)], None, B, lo, kv_all=kv(key))
             pg.release(up)
         gn = m.head[0]   # :148-151: default eps, no activation
         a = pg.alloc((B, L, cs[0]))
@@ -146,6 +150,13 @@ class SDUNet_CAR(_PackedModel):
             self.up_blocks.append(nn.ModuleList(layers))
         self.head = nn.Sequential(nn.GroupNorm(32, cs[0]), nn.Conv1d(cs[0], traj_dim, 3, 1, 1))
         self.embed_cols = 0   # no per-step time-bias row (see SDProgram)
+        # column layout of the stacked condition GEMM: 14 C columns (7 tokens x [K | V]) per executed block
+        self.kv_offsets: Dict[str, int] = {}
+        off = 0
+        for key, blk in self.executed_blocks():
+            self.kv_offsets[key] = off
+            off += N_COND * 2 * blk.out_c
+        self.kv_cols = off
         self._init_cache()
 
     def executed_blocks(self):
@@ -163,6 +174,9 @@ class SDUNet_CAR(_PackedModel):
         with torch.no_grad():
             for key, blk in self.executed_blocks():
                 blk.pack(key, dtype, out)
+            keys = [key for key, _ in self.executed_blocks()]
+            out["kv_all.w"] = torch.cat([out.pop(key + "kvc.w") for key in keys], dim=0).contiguous()
+            out["kv_all.b"] = torch.cat([out.pop(key + "kvc.b") for key in keys]).contiguous()
             for i in range(self.stages):
                 out[f"down_blocks.{i}.down.w"] = engine.pack_conv_weight(self.down_blocks[i][self.res_blocks].weight, dtype)
         return out

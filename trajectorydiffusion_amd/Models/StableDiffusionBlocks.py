@@ -125,11 +125,17 @@ class CrossAttentionRes(_HipBlock):
         c = self.out_c
         mh = self.multihead_attn
         out[key + "conv1.w"] = engine.pack_conv_weight(self.stage1[2].weight, dtype)
-        out[key + "cond.w"] = self.cond_proj[0].weight.detach().to(dtype).contiguous()
         out[key + "q.w"] = mh.in_proj_weight.detach()[:c].to(dtype).contiguous()
-        out[key + "kv.w"] = mh.in_proj_weight.detach()[c:].to(dtype).contiguous()
         out[key + "q.b"] = mh.in_proj_bias.detach()[:c].float().contiguous()
-        out[key + "kv.b"] = mh.in_proj_bias.detach()[c:].float().contiguous()
+        # cond_proj (:53-56,75) and the K | V input projections of the attention (:77) are both linear in the condition vector with
+        # nothing in between: one composite map per token n, kv[b, n, :] = (W_kv W_cp[n]) cond[b] + (W_kv b_cp[n] + b_kv), formed in
+        # fp64 and rounded once.  14 C x 896 instead of (7 C x 896) + (2 C x C): fewer FLOPs from C = 512 up, one GEMM instead of two,
+        # and every block's map can be stacked into ONE GEMM per denoise step (SDUNet_CAR).
+        wc = self.cond_proj[0].weight.detach().double().view(N_COND, c, -1)
+        bc = self.cond_proj[0].bias.detach().double().view(N_COND, c)
+        wkv, bkv = mh.in_proj_weight.detach()[c:].double(), mh.in_proj_bias.detach()[c:].double()
+        out[key + "kvc.w"] = torch.einsum("jc,nck->njk", wkv, wc).reshape(N_COND * 2 * c, -1).to(dtype).contiguous()
+        out[key + "kvc.b"] = (torch.einsum("jc,nc->nj", wkv, bc) + bkv).reshape(-1).float().contiguous()
         out[key + "o.w"] = mh.out_proj.weight.detach().to(dtype).contiguous()
         w2 = engine.pack_conv_weight(self.stage2[2].weight, dtype)
         if self.has_shortcut:
@@ -139,11 +145,12 @@ class CrossAttentionRes(_HipBlock):
             out[key + "conv2.w"] = w2
 
     # ---- program ---------------------------------------------------------------------------------------------------------------
-    def emit(self, pg: engine.Program, packed: Dict[str, torch.Tensor], key: str, srcs: Sequence[Tuple[torch.Tensor, int]], cond: torch.Tensor,
-             B: int, L: int) -> torch.Tensor:
+    def emit(self, pg: engine.Program, packed: Dict[str, torch.Tensor], key: str, srcs: Sequence[Tuple[torch.Tensor, int]],
+             cond: Optional[torch.Tensor], B: int, L: int, kv_all: Optional[Tuple[torch.Tensor, int]] = None) -> torch.Tensor:
         """Record forward() over channels-last rows.  srcs = the raw input as [(tensor (B, L, C_k), C_k), ...] (two entries = the
-        decoder's channel concat, StableDiffusion.py:200, never materialised); cond (B, 896) in the program's dtype.
-        Returns the raw output (B, L, out_c)."""
+        decoder's channel concat, StableDiffusion.py:200, never materialised).  The K | V rows of the 7 condition tokens come either
+        from kv_all = (matrix (B, cols), first column of this block's 14 C columns), filled by the caller's stacked GEMM, or from
+        this block's own composite GEMM on cond (B, 896) in the program's dtype.  Returns the raw output (B, L, out_c)."""
         cin, c = sum(ck for _, ck in srcs), self.out_c
         if cin != self.in_c:
             raise TdxError(f"{key}: sources carry {cin} channels, block expects {self.in_c}")
@@ -163,31 +170,29 @@ class CrossAttentionRes(_HipBlock):
         h = pg.alloc((B, L, c))
         pg.conv([Seg(a1, cin, cin, L)], packed[key + "conv1.w"], fp32_param(conv1.bias, key + "stage1.2.bias"), h, c, B, L, c, name=key + "conv1")
         pg.release(a1)
-        # condition tokens (:75) and their K | V projections (rows = B * 7 tokens)
-        ctok = pg.alloc((B, N_COND * c))
-        pg.conv([Seg(cond, cond.shape[1], cond.shape[1], 1, taps=1)], packed[key + "cond.w"], fp32_param(self.cond_proj[0].bias, key + "cond_proj.0.bias"),
-                ctok, N_COND * c, B, 1, N_COND * c, name=key + "cond_proj")
-        kv = pg.alloc((B, N_COND, 2 * c))
-        pg.conv([Seg(ctok, c, c, 1, taps=1)], packed[key + "kv.w"], packed[key + "kv.b"], kv, 2 * c, B * N_COND, 1, 2 * c, name=key + "kv_proj")
-        pg.release(ctok)
+        # K | V rows of the condition tokens (:75,77)
+        if kv_all is None:
+            kvm, kv_off = pg.alloc((B, N_COND * 2 * c)), 0
+            pg.conv([Seg(cond, cond.shape[1], cond.shape[1], 1, taps=1)], packed[key + "kvc.w"], packed[key + "kvc.b"], kvm, N_COND * 2 * c, B, 1,
+                    N_COND * 2 * c, name=key + "kv_proj")
+        else:
+            kvm, kv_off = kv_all
         # q projection, attention core, out projection + residual (:77)
         q = pg.alloc((B, L, c))
         pg.conv([Seg(h, c, c, L, taps=1)], packed[key + "q.w"], packed[key + "q.b"], q, c, B, L, c, name=key + "q_proj")
         att = pg.alloc((B, L, c))
-        pg.call(key + "attn", pg.lib.tdx_cross_attention, q.data_ptr(), c, kv.data_ptr(), 2 * c, att.data_ptr(), c, B, L, N_COND, c, self.num_heads,
-                pg.code, keep=[q, kv, att])
+        pg.call(key + "attn", pg.lib.tdx_cross_attention, q.data_ptr(), c, kvm.data_ptr() + kv_off * kvm.element_size(), 2 * c, kvm.shape[1],
+                att.data_ptr(), c, B, L, N_COND, c, self.num_heads, pg.code, keep=[q, kvm, att])
         pg.release(q)
-        pg.release(kv)
-        x2 = pg.alloc((B, L, c))
-        pg.conv([Seg(att, c, c, L, taps=1)], packed[key + "o.w"], fp32_param(mh.out_proj.bias, key + "multihead_attn.out_proj.bias"), x2, c, B, L, c,
-                res=h, res_ld=c, name=key + "out_proj")
+        if kv_all is None:
+            pg.release(kvm)
+        # out projection + residual (:77), with stage2's GroupNorm + Swish (:80) as the GEMM's consumer: x2 itself is never needed
+        a2 = pg.alloc((B, L, c))
+        pg.conv([Seg(att, c, c, L, taps=1)], packed[key + "o.w"], fp32_param(mh.out_proj.bias, key + "multihead_attn.out_proj.bias"), None, c, B, L, c,
+                res=h, res_ld=c, name=key + "out_proj", gn=engine.GnSpec(gn2, key + "stage2.0", 0, c // self.norm_groups, ACT_SWISH, a2, c, 0))
         pg.release(att)
         pg.release(h)
-        # stage2 (:80) + shortcut (:72,82)
-        a2 = pg.alloc((B, L, c))
-        pg.groupnorm(x2, c, a2, c, 0, fp32_param(gn2.weight, key + "stage2.0.weight"), fp32_param(gn2.bias, key + "stage2.0.bias"), 0, B, L, c,
-                     self.norm_groups, gn2.eps, ACT_SWISH, name=key + "gn2")
-        pg.release(x2)
+        # stage2's conv + shortcut (:72,80,82)
         out = pg.alloc((B, L, c))
         segs = [Seg(a2, c, c, L)]
         if self.has_shortcut:

@@ -1625,8 +1625,14 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   dma_ok = dma_ok && (int64_t)kDmaRows * k * es < (1ll << 31);
   dma_ok = dma_ok && d->cout % vec == 0 && (!d->out || (d->out_off % vec == 0 && d->out_ld % vec == 0)) && (!d->res || d->res_ld % vec == 0);
   dma_ok = dma_ok && (int64_t)(kDmaRows + 16) * d->out_ld * es < (1ll << 31);  // 32-bit in-tile store offsets
-  const int tc = (d->cout % 256 == 0 && !(g_force & 128)) ? 256 : 128;  // (128-wide tiles for Cout = 256 measured 17 % slower)
-  const int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
+  int tc = (d->cout % 256 == 0 && !(g_force & 128)) ? 256 : 128;  // (128-wide tiles for Cout = 256 measured 17 % slower)
+  int64_t tiles = (int64_t)((a.N + kDmaRows - 1) / kDmaRows) * ((d->cout + tc - 1) / tc);
+  // Short trajectories under wide layers (the latent path: 3 .. 24 rows per trajectory, 256 .. 1024 channels): too few 256-wide
+  // tiles for the LDS-DMA kernels, but 128 x 128 tiles (4x as many, two workgroups per CU) fill the chip.  Same K order per output.
+  if (tc == 256 && tiles < 128 && !(g_force & 8)) {
+    tc = 128;
+    tiles *= 2;
+  }
   // narrow outputs: 128-row tiles, two workgroups per CU (epilogue of one under the K loop of the other)
   const int tr = (tc == 128 && !(g_force & 8)) ? 128 : 256;
   ch = Choice{0, tc, tr, false};

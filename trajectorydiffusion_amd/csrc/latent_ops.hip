@@ -6,56 +6,77 @@
 namespace {
 
 // ---- cross-attention core (Models/StableDiffusionBlocks.py:74, nn.MultiheadAttention(out_dim, 8) with 7 key/value tokens) ----
-// One wave per query row (b, l).  A lane owns CPL = C / 64 consecutive channels, so a head (C / 8 channels) is a group of 8 lanes:
-// the N scores of a head are partial dot products reduced with three xor-shuffles, softmax and the weighted sum of V stay in
-// registers.  K | V rows of the trajectory (N x 2C) are staged once per workgroup in LDS as fp32.
-template <typename T, int CPL>
-__global__ __launch_bounds__(256) void cross_attention_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ kv, int kv_ld,
-                                                             T* __restrict__ out, int out_ld, int B, int L, int N, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float kvs[];  // [N][2C]
-  constexpr int C = CPL * 64;
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < N * 2 * C; i += 256) {
-    const int n = i / (2 * C), c = i - n * 2 * C;
-    kvs[i] = Elem<T>::ld(kv + ((size_t)b * N + n) * kv_ld + c);
+// HBM-bound: q in, out out, K | V of the trajectory once.  A lane owns one 16-byte channel vector of a query row, so a row takes
+// LPR = C / VEC lanes and a head (C / 8 channels) LPR / 8 of them (2 .. 32, inside one wave): the N scores of a head are partial
+// dot products reduced with xor-shuffles; softmax and the weighted sum of V stay in registers.  A workgroup serves TB whole
+// trajectories (TB * L rows, 256 / LPR rows per pass); their K | V rows (TB x N x 2C) are staged once in LDS in the storage
+// dtype with 16-byte loads.  kv_bs = element stride between trajectories (the K | V rows of all blocks of the model come out of
+// one GEMM as column slices of one wide matrix).
+template <typename T>
+__global__ __launch_bounds__(256) void cross_attention_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ kv, int kv_ld, long kv_bs,
+                                                             T* __restrict__ out, int out_ld, int B, int L, int N, int C, int TB, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kv_raw[];
+  constexpr int VEC = Elem<T>::kVec;
+  T* kvs = reinterpret_cast<T*>(kv_raw);   // [TB][N][2C]
+  const int b0 = blockIdx.x * TB;
+  const int ntb = min(TB, B - b0);
+  const int vpt = 2 * C / VEC;             // 16-byte vectors per token row
+  for (int i = threadIdx.x; i < ntb * N * vpt; i += 256) {
+    const int v = i % vpt, tn = i / vpt;
+    const int n = tn % N, tb = tn / N;
+    *reinterpret_cast<u32x4*>(kvs + ((size_t)tn * 2 * C) + v * VEC) =
+        *reinterpret_cast<const u32x4*>(kv + (size_t)(b0 + tb) * kv_bs + (size_t)n * kv_ld + v * VEC);
   }
   __syncthreads();
-  const int c0 = lane * CPL;
-  for (int l = wave; l < L; l += 4) {
-    const T* qr = q + ((size_t)b * L + l) * q_ld + c0;
-    float qv[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) qv[j] = Elem<T>::ld(qr + j) * scale;
+  const int lpr = C / VEC, lph = lpr >> 3, rpp = 256 / lpr;
+  const int col = threadIdx.x % lpr, rip = threadIdx.x / lpr;
+  const int rows = ntb * L;
+  for (int r0 = 0; r0 < rows; r0 += rpp) {
+    const int r = r0 + rip;
+    const bool live = r < rows;
+    const int rc = live ? r : rows - 1;    // dead lanes shadow the last row: the shuffles below stay convergent
+    const int tb = rc / L, l = rc - tb * L;
+    const size_t grow = (size_t)(b0 + tb) * L + l;
+    float qv[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(q + grow * q_ld + col * VEC), qv);
+    const T* kt = kvs + (size_t)tb * N * 2 * C + col * VEC;
     float s[8];
     float m = -3.0e38f;
-    for (int n = 0; n < N; ++n) {   // N <= 8
-      float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) d = fmaf(qv[j], kvs[n * 2 * C + c0 + j], d);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      s[n] = d;
-      m = fmaxf(m, d);
+    for (int n = 0; n < 8; ++n) {
+      s[n] = -3.0e38f;
+      if (n < N) {
+        float kf[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(kt + (size_t)n * 2 * C), kf);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d = fmaf(qv[j], kf[j], d);
+        for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, 64);
+        s[n] = d * scale;
+        m = fmaxf(m, s[n]);
+      }
     }
     float den = 0.f;
-    for (int n = 0; n < N; ++n) {
-      s[n] = __expf(s[n] - m);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      s[n] = n < N ? __expf(s[n] - m) : 0.f;
       den += s[n];
     }
     const float inv = 1.0f / den;
-    float o[CPL];
+    float o[VEC];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) o[j] = 0.f;
-    for (int n = 0; n < N; ++n) {
-      const float pw = s[n] * inv;
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) o[j] = fmaf(pw, kvs[n * 2 * C + C + c0 + j], o[j]);
+    for (int n = 0; n < 8; ++n) {
+      if (n < N) {
+        float vf[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(kt + (size_t)n * 2 * C + C), vf);
+        const float pw = s[n] * inv;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = fmaf(pw, vf[j], o[j]);
+      }
     }
-    T* orow = out + ((size_t)b * L + l) * out_ld + c0;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) orow[j] = (T)o[j];
+    if (live) *reinterpret_cast<u32x4*>(out + grow * out_ld + col * VEC) = Elem<T>::pack(o);
   }
 }
 
@@ -232,6 +253,118 @@ __global__ __launch_bounds__(256) void head_conv_n_kernel(const T* __restrict__ 
   }
 }
 
+// Register-stationary forms of the two kernels above (C0 a multiple of the 16-byte vector): a lane owns one channel vector, keeps
+// its weights in registers and walks `iters` rows; a per-thread weight reload per output (the simple kernels) is bound by
+// vector-memory instruction issue, 20x off the HBM time.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void stem_conv_n_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             T* __restrict__ out, int B, int L, int C0, int iters) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int vpr = C0 / VEC;                    // host: a power of two <= 256
+  const int cv = threadIdx.x % vpr, rstep = 256 / vpr;
+  float wr[VEC][CIN * 3], bs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    bs[j] = bias[cv * VEC + j];
+#pragma unroll
+    for (int k = 0; k < CIN * 3; ++k) wr[j][k] = w[(cv * VEC + j) * CIN * 3 + k];
+  }
+  const long nrows = (long)B * L;
+  const long r0 = (long)blockIdx.x * rstep * iters + threadIdx.x / vpr;
+  for (int it = 0; it < iters; ++it) {
+    const long n = r0 + (long)it * rstep;
+    if (n >= nrows) break;
+    const int l = (int)(n % L);
+    const long b = n / L;
+    float xin[CIN * 3];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int u = l + t - 1;
+        xin[ci * 3 + t] = (u >= 0 && u < L) ? x[((size_t)b * CIN + ci) * L + u] : 0.f;
+      }
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float a = bs[j];
+#pragma unroll
+      for (int k = 0; k < CIN * 3; ++k) a = fmaf(wr[j][k], xin[k], a);   // same order as stem_conv_n_kernel
+      v[j] = a;
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)n * C0 + cv * VEC) = Elem<T>::pack(v);
+  }
+}
+// lpr = C0 / VEC lanes (a power of two <= 64) share a row; sums reduced with xor-shuffles inside the row's lanes.
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_conv_n_vec_kernel(const T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int B, int L, int C0, int lpr, int iters) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int col = threadIdx.x % lpr, rstep = 256 / lpr;
+  float wr[COUT][3][VEC];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) wr[o][t][j] = w[((size_t)o * C0 + col * VEC + j) * 3 + t];
+  const long nrows = (long)B * L;
+  const long r0 = (long)blockIdx.x * rstep * iters + threadIdx.x / lpr;
+  for (int it = 0; it < iters; ++it) {
+    const long n = r0 + (long)it * rstep;
+    const bool live = n < nrows;   // dead lanes shadow the last row: the shuffles stay convergent
+    const long nn = live ? n : nrows - 1;
+    const int l = (int)(nn % L);
+    const long b = nn / L;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int u = l + t - 1;
+      const bool ok = u >= 0 && u < L;
+      float v[VEC];
+      Elem<T>::unpack(ok ? *reinterpret_cast<const u32x4*>(a + ((size_t)b * L + u) * C0 + col * VEC) : (u32x4){0u, 0u, 0u, 0u}, v);
+#pragma unroll
+      for (int o = 0; o < COUT; ++o)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[o] = fmaf(wr[o][t][j], v[j], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      float s = acc[o];
+      for (int d = 1; d < lpr; d <<= 1) s += __shfl_xor(s, d, 64);
+      if (live && col == 0) out[((size_t)b * COUT + o) * L + l] = s + bias[o];
+    }
+  }
+}
+template <typename T>
+static bool launch_stem_vec(const float* x, const float* w, const float* bias, T* out, int B, int L, int cin, int C0, hipStream_t st) {
+  const int vpr = C0 / Elem<T>::kVec, iters = 8;
+  const long rows = (long)B * L, per_block = (long)(256 / vpr) * iters;
+  const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
+  switch (cin) {
+    case 1: hipLaunchKernelGGL((stem_conv_n_vec_kernel<T, 1>), grid, dim3(256), 0, st, x, w, bias, out, B, L, C0, iters); return true;
+    case 2: hipLaunchKernelGGL((stem_conv_n_vec_kernel<T, 2>), grid, dim3(256), 0, st, x, w, bias, out, B, L, C0, iters); return true;
+    case 3: hipLaunchKernelGGL((stem_conv_n_vec_kernel<T, 3>), grid, dim3(256), 0, st, x, w, bias, out, B, L, C0, iters); return true;
+    case 4: hipLaunchKernelGGL((stem_conv_n_vec_kernel<T, 4>), grid, dim3(256), 0, st, x, w, bias, out, B, L, C0, iters); return true;
+    default: return false;
+  }
+}
+template <typename T>
+static bool launch_head_vec(const T* a, const float* w, const float* bias, float* out, int B, int L, int C0, int cout, int lpr, hipStream_t st) {
+  const int iters = 8;
+  const long rows = (long)B * L, per_block = (long)(256 / lpr) * iters;
+  const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
+  switch (cout) {
+    case 1: hipLaunchKernelGGL((head_conv_n_vec_kernel<T, 1>), grid, dim3(256), 0, st, a, w, bias, out, B, L, C0, lpr, iters); return true;
+    case 2: hipLaunchKernelGGL((head_conv_n_vec_kernel<T, 2>), grid, dim3(256), 0, st, a, w, bias, out, B, L, C0, lpr, iters); return true;
+    case 3: hipLaunchKernelGGL((head_conv_n_vec_kernel<T, 3>), grid, dim3(256), 0, st, a, w, bias, out, B, L, C0, lpr, iters); return true;
+    case 4: hipLaunchKernelGGL((head_conv_n_vec_kernel<T, 4>), grid, dim3(256), 0, st, a, w, bias, out, B, L, C0, lpr, iters); return true;
+    default: return false;
+  }
+}
+
 }  // namespace
 
 extern "C" int tdx_stem_conv_n(const float* x, const float* w, const float* bias, void* out, int32_t B, int32_t L, int32_t cin, int32_t C0,
@@ -239,6 +372,16 @@ extern "C" int tdx_stem_conv_n(const float* x, const float* w, const float* bias
   TDX_CHECK_ARG(x && w && bias && out, "tdx_stem_conv_n: null pointer");
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_stem_conv_n: bad dtype %d", dtype);
   TDX_CHECK_ARG(B > 0 && L > 0 && C0 > 0 && cin >= 1 && cin <= 8, "tdx_stem_conv_n: bad shape B=%d L=%d cin=%d C0=%d (cin 1..8)", B, L, cin, C0);
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  const int vpr = C0 % vec == 0 ? C0 / vec : 0;
+  if (vpr >= 1 && vpr <= 256 && (vpr & (vpr - 1)) == 0 && cin <= 4 && ((uintptr_t)out & 15) == 0) {
+    const bool ok = dtype == TDX_F32 ? launch_stem_vec<float>(x, w, bias, (float*)out, B, L, cin, C0, (hipStream_t)stream)
+                                     : launch_stem_vec<__bf16>(x, w, bias, (__bf16*)out, B, L, cin, C0, (hipStream_t)stream);
+    if (ok) {
+      TDX_CHECK_LAUNCH("stem_conv_n_vec_kernel");
+      return TDX_OK;
+    }
+  }
   const long n = (long)B * L * C0;
   const dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == TDX_F32) hipLaunchKernelGGL(stem_conv_n_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, (float*)out, B, L, cin, C0);
@@ -253,6 +396,16 @@ extern "C" int tdx_head_conv_n(const void* a, const float* w, const float* bias,
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_head_conv_n: bad dtype %d", dtype);
   TDX_CHECK_ARG(B > 0 && L > 0 && C0 > 0 && cout >= 1 && cout <= 8, "tdx_head_conv_n: bad shape B=%d L=%d C0=%d cout=%d (cout 1..8)", B, L, C0, cout);
   const long rows = (long)B * L;
+  const int vec = dtype == TDX_F32 ? 4 : 8;
+  const int lpr = C0 % vec == 0 ? C0 / vec : 0;
+  if (lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && cout <= 4 && ((uintptr_t)a & 15) == 0) {
+    const bool ok = dtype == TDX_F32 ? launch_head_vec<float>((const float*)a, w, bias, out, B, L, C0, cout, lpr, (hipStream_t)stream)
+                                     : launch_head_vec<__bf16>((const __bf16*)a, w, bias, out, B, L, C0, cout, lpr, (hipStream_t)stream);
+    if (ok) {
+      TDX_CHECK_LAUNCH("head_conv_n_vec_kernel");
+      return TDX_OK;
+    }
+  }
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == TDX_F32) hipLaunchKernelGGL(head_conv_n_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, w, bias, out, B, L, C0, cout);
   else hipLaunchKernelGGL(head_conv_n_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, w, bias, out, B, L, C0, cout);
@@ -260,41 +413,48 @@ extern "C" int tdx_head_conv_n(const void* a, const float* w, const float* bias,
   return TDX_OK;
 }
 
-extern "C" int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, int32_t kv_ld, void* out, int32_t out_ld, int32_t B, int32_t L,
-                                   int32_t N, int32_t C, int32_t heads, int32_t dtype, void* stream) {
+extern "C" int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, int32_t kv_ld, int64_t kv_bs, void* out, int32_t out_ld, int32_t B,
+                                   int32_t L, int32_t N, int32_t C, int32_t heads, int32_t dtype, void* stream) {
   TDX_CHECK_ARG(q && kv && out && B > 0 && L > 0, "tdx_cross_attention: bad arguments");
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_cross_attention: bad dtype %d", dtype);
   TDX_CHECK_ARG(N >= 1 && N <= 8, "tdx_cross_attention: N=%d key/value tokens (1..8)", N);
   TDX_CHECK_ARG(heads == 8, "tdx_cross_attention: heads=%d (the lane layout is built for 8 heads, StableDiffusion.py:139)", heads);
   TDX_CHECK_ARG(C == 128 || C == 256 || C == 512 || C == 1024, "tdx_cross_attention: C=%d (128, 256, 512 or 1024)", C);
-  TDX_CHECK_ARG(q_ld >= C && out_ld >= C && kv_ld >= 2 * C, "tdx_cross_attention: row pitches too small");
+  const int es = dtype == TDX_F32 ? 4 : 2, vec = 16 / es;
+  TDX_CHECK_ARG(q_ld >= C && out_ld >= C && kv_ld >= 2 * C && kv_bs >= (int64_t)N * kv_ld, "tdx_cross_attention: row pitches too small");
+  TDX_CHECK_ARG(q_ld % vec == 0 && out_ld % vec == 0 && kv_ld % vec == 0 && kv_bs % vec == 0 && (((uintptr_t)q | (uintptr_t)kv | (uintptr_t)out) & 15) == 0,
+                "tdx_cross_attention: pitches and pointers must be 16-byte aligned");
+  // trajectories per workgroup: fill whole passes of 256 / (C / vec) rows, within 32 KB of LDS (one trajectory may need up to 56 KB)
+  const int rpp = 256 / (C / vec);
+  int g = L, r = rpp;
+  while (r) { const int t = g % r; g = r; r = t; }   // gcd(L, rpp)
+  int tb = rpp / g;
+  const size_t per_traj = (size_t)N * 2 * C * es;
+  while (tb > 1 && tb * per_traj > 32 * 1024) tb >>= 1;   // (more resident workgroups hide the staging latency better than fuller passes)
+  if (tb > B) tb = B;
+  const size_t lds = tb * per_traj;
   const float scale = 1.0f / sqrtf((float)(C / heads));
-  const size_t lds = (size_t)N * 2 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define TDX_XA(T, CPL)                                                                                                                    \
-  do {                                                                                                                                    \
-    static bool attr = false;                                                                                                             \
-    if (!attr) {                                                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attention_kernel<T, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              8 * 2 * CPL * 64 * 4) != hipSuccess)                                                                        \
-        TDX_FAIL(TDX_ERR_HIP, "tdx_cross_attention: cannot reserve LDS");                                                                 \
-      attr = true;                                                                                                                        \
-    }                                                                                                                                     \
-    hipLaunchKernelGGL((cross_attention_kernel<T, CPL>), dim3((unsigned)B), dim3(256), lds, st, (const T*)q, q_ld, (const T*)kv, kv_ld,   \
-                       (T*)out, out_ld, B, L, N, scale);                                                                                  \
-  } while (0)
+  const dim3 grid((unsigned)((B + tb - 1) / tb));
   if (dtype == TDX_F32) {
-    if (C == 128) TDX_XA(float, 2);
-    else if (C == 256) TDX_XA(float, 4);
-    else if (C == 512) TDX_XA(float, 8);
-    else TDX_XA(float, 16);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        TDX_FAIL(TDX_ERR_HIP, "tdx_cross_attention: cannot reserve LDS");
+      attr = true;
+    }
+    hipLaunchKernelGGL(cross_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)q, q_ld, (const float*)kv, kv_ld, (long)kv_bs, (float*)out,
+                       out_ld, B, L, N, C, tb, scale);
   } else {
-    if (C == 128) TDX_XA(__bf16, 2);
-    else if (C == 256) TDX_XA(__bf16, 4);
-    else if (C == 512) TDX_XA(__bf16, 8);
-    else TDX_XA(__bf16, 16);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attention_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        TDX_FAIL(TDX_ERR_HIP, "tdx_cross_attention: cannot reserve LDS");
+      attr = true;
+    }
+    hipLaunchKernelGGL(cross_attention_kernel<__bf16>, grid, dim3(256), lds, st, (const __bf16*)q, q_ld, (const __bf16*)kv, kv_ld, (long)kv_bs,
+                       (__bf16*)out, out_ld, B, L, N, C, tb, scale);
   }
-#undef TDX_XA
   TDX_CHECK_LAUNCH("cross_attention_kernel");
   return TDX_OK;
 }

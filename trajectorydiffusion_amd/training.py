@@ -8,8 +8,9 @@ data gradients run on the forward conv kernel (tdx_conv_gemm on dy with repacked
 tdx_conv_wgrad, GroupNorm+Swish on tdx_groupnorm_act_bwd, and so on (include/trajdiff_hip.h, "Training-step building
 blocks").  Activations are saved (no workspace reuse), statistics are recomputed.
 
-torch does plumbing only: device memory, padded stand-ins and bias sums (small copy_ ops into fixed buffers),
-embedding-row gathers, layout changes of the (B, 2, L) model input/output, and zeroing of gradient buffers.
+torch does plumbing only: device memory, padded stand-ins and bias sums (small copy_ ops into fixed buffers), dtype /
+contiguity fixes of the step's inputs, and zeroing of gradient buffers.  The embedding-row gathers and the layout changes of
+the (B, 2, L) model input / output are library launches too (tdx_embed_gather, tdx_chanfirst_to_rows, tdx_rows_to_chanfirst).
 
 Not covered: bf16 training (the reference trains in fp32).
 """
@@ -303,6 +304,11 @@ class TrainStep:
         emb = m.embed_block
         # ---- embedding (TrajUNetBlocks.py:45-62) ----
         self.pe, self.catvec, self.num4 = self._new(B, 1, 128), self._new(B, 1, 1280), self._new(B, 1, 4)
+        # tdx_embed_gather also writes the inference path's LeakyReLU(wide_fc(num)) slice; training runs wide_fc as a GEMM (it needs the
+        # weight gradient), so that slice lands in a scratch row buffer
+        self._gather_scratch = torch.empty((B, 1024), dtype=torch.float32, device=self.dev)
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._pos_enc = None
         t0, t2 = emb.time_embed_layers[0], emb.time_embed_layers[2]
         cf, d1, d3 = emb.categorical_fc, emb.deep_fc[1], emb.deep_fc[3]
         h1 = self._new(B, 1, 128)
@@ -462,25 +468,29 @@ class TrainStep:
             raise TdxError(f"TrainStep: expected x_t of shape {(B, 2, L)}, got {tuple(x_t.shape)}")
         for v in (x_t, t, cat, num):
             _lib.require_device(v, "TrainStep input")
-        bad = (t.min() < 0) | (t.max() >= emb.pos_enc.shape[0]) | (cat[:, :4].min() < 0) | (cat[:, :4].max() > 255) | (cat[:, 4].min() < 0) | \
-            (cat[:, 4].max() > 32)
-        if bool(bad):                                   # the step's only host synchronisation
-            raise IndexError("TrainStep: time step or categorical attribute out of range")
+        F32, st, lib = _lib.TDX_F32, _lib.stream_ptr(), self.lib
         with torch.no_grad():
             self._refresh_packed_weights()
             self._passes += 1
             self.rng[0] = self._passes
-            # plumbing: layouts and embedding-row gathers
-            self.x4.zero_()
-            self.x4[:, :, :2].copy_(x_t.permute(0, 2, 1))
-            self.pe[:, 0, :].copy_(emb.pos_enc.to(self.dev)[t])
+            # layouts and embedding-row gathers, through the library like everything else (dtype / contiguity fixes are the only
+            # torch ops left): (B, 2, L) -> zero-padded rows (B, L, 4); pos_enc[t] and the five embedding rows; num -> (B, 4)
+            x_c, num_c = x_t.to(torch.float32).contiguous(), num.to(torch.float32).contiguous()
+            t_c = t.to(torch.int64).contiguous()
             self.cat.copy_(cat)
-            self.catvec[:, 0, :1024].copy_(emb.cell_index_embedder.weight.detach()[cat[:, :4]].flatten(1))
-            self.catvec[:, 0, 1024:].copy_(emb.day_embedder.weight.detach()[cat[:, 4]])
-            self.num4.zero_()
-            self.num4[:, 0, :3].copy_(num)
+            if self._pos_enc is None or self._pos_enc.device != self.dev:
+                self._pos_enc = emb.pos_enc.to(self.dev).contiguous()
+            _lib.check(lib.tdx_chanfirst_to_rows(x_c.data_ptr(), self.x4.data_ptr(), B, 2, L, 4, F32, st), "x -> rows")
+            _lib.check(lib.tdx_embed_gather(t_c.data_ptr(), self.cat.data_ptr(), num_c.data_ptr(), self._pos_enc.data_ptr(), self._pos_enc.shape[0],
+                                            emb.cell_index_embedder.weight.data_ptr(), emb.day_embedder.weight.data_ptr(),
+                                            emb.wide_fc.weight.data_ptr(), emb.wide_fc.bias.data_ptr(), self.pe.data_ptr(), self.catvec.data_ptr(),
+                                            self._gather_scratch.data_ptr(), B, self._err.data_ptr(), st), "tdx_embed_gather")
+            _lib.check(lib.tdx_chanfirst_to_rows(num_c.data_ptr(), self.num4.data_ptr(), B, 3, 1, 4, F32, st), "num -> rows")
+            if int(self._err.item()):                       # the step's only host synchronisation
+                self._err.zero_()
+                raise IndexError("TrainStep: time step or categorical attribute out of range")
             self.fw.run()
-            self.pred.copy_(self.out4[:, :, :2].permute(0, 2, 1))
+            _lib.check(lib.tdx_rows_to_chanfirst(self.out4.data_ptr(), 4, self.pred.data_ptr(), B, 2, L, F32, st), "rows -> eps_hat")
         return self.pred
 
     def backward(self, dpred: torch.Tensor, sync_group=False, bucket_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
@@ -499,7 +509,9 @@ class TrainStep:
             for n, g in self.grads.items():
                 if n not in self.params:
                     g.zero_()
-            self.G(self.out4)[:, :, :2].copy_(dpred.permute(0, 2, 1))
+            dp = dpred.to(torch.float32).contiguous()
+            _lib.check(self.lib.tdx_chanfirst_to_rows(dp.data_ptr(), self.G(self.out4).data_ptr(), self.B, 2, self.L, 4, _lib.TDX_F32, _lib.stream_ptr()),
+                       "dpred -> rows")
             if not sync:
                 self.bw.run()
                 self._fold_padded()

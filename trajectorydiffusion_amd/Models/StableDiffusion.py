@@ -181,11 +181,11 @@ class SDUNet_CAR(_PackedModel):
                 out[f"down_blocks.{i}.down.w"] = engine.pack_conv_weight(self.down_blocks[i][self.res_blocks].weight, dtype)
         return out
 
-    def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> SDProgram:
+    def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None, slot: int = 0) -> SDProgram:
         """split_embed is accepted for the sampler's sake and changes nothing here (see SDProgram)."""
         dtype = self.compute_dtype if dtype is None else dtype
         self.packed_weights(dtype)
-        key = (B, L, dtype, device, split_embed, self.low_latency)
+        key = (B, L, dtype, device, split_embed, self.low_latency) + ((slot,) if slot else ())   # slot: distinct instances of one shape (batch slices that run concurrently)
         prog = self._programs.get(key)
         if prog is None:
             prog = SDProgram(self, B, L, dtype, device)

@@ -268,10 +268,10 @@ class TrajUNet(_PackedModel):
             out["embed_proj.b"] = torch.cat([blk.embed_proj.bias.detach() for _, blk in self.executed_resblocks()]).float().contiguous()
         return out
 
-    def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None) -> UNetProgram:
+    def program(self, B: int, L: int, device: torch.device, split_embed: bool = False, dtype: Optional[torch.dtype] = None, slot: int = 0) -> UNetProgram:
         dtype = self.compute_dtype if dtype is None else dtype
         self.packed_weights(dtype)  # refresh (drops stale programs) before the cache lookup
-        key = (B, L, dtype, device, split_embed, self.low_latency)
+        key = (B, L, dtype, device, split_embed, self.low_latency) + ((slot,) if slot else ())   # slot: distinct instances of one shape (batch slices that run concurrently)
         prog = self._programs.get(key)
         if prog is None:
             prog = UNetProgram(self, B, L, dtype, device, split_embed)

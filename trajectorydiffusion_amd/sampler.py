@@ -6,6 +6,7 @@ same graph is replayed for every t with no host-side arguments changing.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -14,12 +15,31 @@ from . import _lib, engine
 from ._lib import TdxError
 
 
+class _Shard:
+    """One slice of the batch with its own program, step counter and stream."""
+    __slots__ = ("lo", "n", "prog", "key", "ctr", "coef_cur", "zbuf", "stream", "first_elem")
+
+
+def auto_shards(B: int, low_latency: bool) -> int:
+    """Batch slices that run as concurrent streams inside one denoise step.  The conv GEMMs are bound by LDS / MFMA issue and occupy
+    one workgroup per CU; the GroupNorm, attention and update passes between them are HBM streams that need neither.  With two
+    slices on two streams the HBM passes of one slice run under the GEMMs of the other instead of in series with them.  Slices are
+    independent (no cross-trajectory op) and draw the Philox noise of their global sample indices, so the result is bit-identical
+    to the unsliced run.  Small batches stay whole: their GEMMs need every tile they have."""
+    env = os.environ.get("TDX_SAMPLER_SHARDS")
+    if env:
+        return max(1, int(env))
+    return 2 if (not low_latency and B % 2 == 0 and B >= 2048) else 1
+
+
 class GraphSampler:
-    def __init__(self, dm, model, B: int, L: int, device: torch.device, max_t: int, ddim_steps: Optional[int] = None):
+    def __init__(self, dm, model, B: int, L: int, device: torch.device, max_t: int, ddim_steps: Optional[int] = None,
+                 shards: Optional[int] = None):
         self.dm, self.model, self.B, self.L, self.device = dm, model, B, L, device
         self.lib = _lib.lib()
-        self.prog = model.program(B, L, device, split_embed=True)
-        self._prog_key = (B, L, model.compute_dtype, device, True, model.low_latency)
+        ns = auto_shards(B, getattr(model, "low_latency", False)) if shards is None else int(shards)
+        if ns < 1 or B % ns:
+            raise TdxError(f"sampler: {ns} shards do not divide a batch of {B}")
         self.ddim = ddim_steps is not None
         ab = dm.alpha_bars.view(-1).cpu()
         if self.ddim:
@@ -37,21 +57,33 @@ class GraphSampler:
         self.nsteps = len(ts)
         self.coef_table = coef.to(torch.float32).contiguous().to(device)
         self.step_to_t = ts.to(torch.int32).to(device)
-        self.D = self.prog.x.shape[1]                                 # trajectory channels: 2 (TrajUNet) or 4 (latents)
         self.tbias_table = model.time_bias_table(ts.to(device))       # None: the model has no per-step time-bias row (SDUNet_CAR)
         self._epoch = model.weights_epoch
-        self.coef_cur = torch.zeros(4, dtype=torch.float32, device=device)
-        self.ctr = torch.zeros(4, dtype=torch.int32, device=device)  # {step, seed_lo, seed_hi, -}
-        self.zbuf = torch.zeros((B, self.D, L), dtype=torch.float32, device=device)
+        self.shards = []
+        nb = B // ns
+        for k in range(ns):
+            sh = _Shard()
+            sh.lo, sh.n = k * nb, nb
+            sh.prog = model.program(nb, L, device, split_embed=True, slot=k)
+            sh.key = (nb, L, model.compute_dtype, device, True, model.low_latency) + ((k,) if k else ())
+            sh.ctr = torch.zeros(4, dtype=torch.int32, device=device)  # {step, seed_lo, seed_hi, Philox stream id}
+            sh.coef_cur = torch.zeros(4, dtype=torch.float32, device=device)
+            sh.stream = torch.cuda.Stream(device=device) if ns > 1 else None
+            sh.first_elem = 0
+            self.shards.append(sh)
+        self.prog = self.shards[0].prog
+        self.D = self.prog.x.shape[1]                                 # trajectory channels: 2 (TrajUNet) or 4 (latents)
+        for sh in self.shards:
+            sh.zbuf = torch.zeros((nb, self.D, L), dtype=torch.float32, device=device)
         self.graphs = {}
         self.first_elem = 0
 
     def valid(self) -> bool:
-        """False when the model dropped this sampler's program (parameters moved, dtype/mode changed).  Weight VALUES may
+        """False when the model dropped this sampler's programs (parameters moved, dtype/mode changed).  Weight VALUES may
         change freely: the packed copies are refreshed in place (also after writes through `.data`, which only the norm
         digest sees) and the per-step time rows are re-derived."""
         self.model.packed_weights(self.model.compute_dtype, check_data=True)
-        if self.model._programs.get(self._prog_key) is not self.prog:
+        if any(self.model._programs.get(sh.key) is not sh.prog for sh in self.shards):
             return False
         if self.model.weights_epoch != self._epoch:
             if self.tbias_table is not None:
@@ -59,19 +91,30 @@ class GraphSampler:
             self._epoch = self.model.weights_epoch
         return True
 
-    def _step(self, inject: bool) -> None:
-        p, st = self.prog, _lib.stream_ptr()
-        _lib.check(self.lib.tdx_step_prepare(self.ctr.data_ptr(), self.coef_table.data_ptr(), 4, self.coef_cur.data_ptr(),
+    def _step_shard(self, sh: _Shard, inject: bool) -> None:
+        p, st = sh.prog, _lib.stream_ptr()
+        _lib.check(self.lib.tdx_step_prepare(sh.ctr.data_ptr(), self.coef_table.data_ptr(), 4, sh.coef_cur.data_ptr(),
                                              _lib.ptr(self.tbias_table), self.model.embed_cols, _lib.ptr(p.tbias),
-                                             self.step_to_t.data_ptr(), p.time.data_ptr(), self.B, self.nsteps, st), "tdx_step_prepare")
+                                             self.step_to_t.data_ptr(), p.time.data_ptr(), sh.n, self.nsteps, st), "tdx_step_prepare")
         p.run()
         n = p.x.numel()
         if self.ddim:
-            _lib.check(self.lib.tdx_ddim_update(p.x.data_ptr(), p.eps.data_ptr(), self.coef_cur.data_ptr(), n, st), "tdx_ddim_update")
+            _lib.check(self.lib.tdx_ddim_update(p.x.data_ptr(), p.eps.data_ptr(), sh.coef_cur.data_ptr(), n, st), "tdx_ddim_update")
         else:
-            _lib.check(self.lib.tdx_ddpm_update(p.x.data_ptr(), p.eps.data_ptr(), self.zbuf.data_ptr() if inject else None,
-                                                self.coef_cur.data_ptr(), n, 0, self.ctr.data_ptr(), self.first_elem, st),
+            _lib.check(self.lib.tdx_ddpm_update(p.x.data_ptr(), p.eps.data_ptr(), sh.zbuf.data_ptr() if inject else None,
+                                                sh.coef_cur.data_ptr(), n, 0, sh.ctr.data_ptr(), sh.first_elem, st),
                        "tdx_ddpm_update")
+
+    def _step(self, inject: bool) -> None:
+        if len(self.shards) == 1:
+            return self._step_shard(self.shards[0], inject)
+        cur = torch.cuda.current_stream()
+        for sh in self.shards:     # fork: each slice's chain of launches on its own stream (also under graph capture: parallel branches)
+            sh.stream.wait_stream(cur)
+            with torch.cuda.stream(sh.stream):
+                self._step_shard(sh, inject)
+        for sh in self.shards:     # join
+            cur.wait_stream(sh.stream)
 
     def _graph(self, inject: bool) -> torch.cuda.CUDAGraph:
         key = (inject, self.first_elem)
@@ -90,37 +133,45 @@ class GraphSampler:
 
     def sample(self, x_T: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor, noise=None, first_sample: int = 0,
                use_graph: bool = True, trace=None) -> torch.Tensor:
-        p = self.prog
         for t, name in ((x_T, "x_T"), (cat_attr, "cat_attr"), (num_attr, "num_attr")):
             _lib.require_device(t, name)
         if tuple(x_T.shape) != (self.B, self.D, self.L):
             raise TdxError(f"sampler built for {(self.B, self.D, self.L)}, got x_T {tuple(x_T.shape)}")
         inject = noise is not None and not self.ddim
         self.first_elem = int(first_sample) * self.D * self.L
-        if self.first_elem % 4:
-            raise TdxError("first_sample * channels * L must be a multiple of 4")
-        p.cat.copy_(cat_attr)   # (before the capture: a model that gathers its attributes inside the step must not see stale indices)
-        p.num.copy_(num_attr)
-        p.time.zero_()
+        for sh in self.shards:
+            sh.first_elem = (int(first_sample) + sh.lo) * self.D * self.L
+            if sh.first_elem % 4:
+                raise TdxError("first_sample * channels * L must be a multiple of 4 (for every batch slice)")
+            p = sh.prog
+            p.cat.copy_(cat_attr[sh.lo:sh.lo + sh.n])   # (before the capture: a model that gathers its attributes inside the step must not see stale indices)
+            p.num.copy_(num_attr[sh.lo:sh.lo + sh.n])
+            p.time.zero_()
         graph = self._graph(inject) if use_graph else None  # (its warm-up step scribbles on x / ctr: load x after)
-        p.x.copy_(x_T)
-        if p.embed_pg is not None:
-            p.embed_pg.run()  # attribute half of every embed_proj, once per call
-        engine.check_err_flag(p.err, "diffusionBackward")
         seed = self.dm._draw_seed()
-        self.ctr.copy_(torch.tensor(self.dm.seed_words(seed), dtype=torch.int32))
+        words = torch.tensor(self.dm.seed_words(seed), dtype=torch.int32)
+        for sh in self.shards:
+            p = sh.prog
+            p.x.copy_(x_T[sh.lo:sh.lo + sh.n])
+            if p.embed_pg is not None:
+                p.embed_pg.run()  # attribute half of every embed_proj, once per call
+            engine.check_err_flag(p.err, "diffusionBackward")
+            sh.ctr.copy_(words)
         for s in range(self.nsteps):
             t = int(self.ts[s])
             if inject and t > 0:
-                self.zbuf.copy_(noise(t) if callable(noise) else noise[t])
+                z = noise(t) if callable(noise) else noise[t]
+                for sh in self.shards:
+                    sh.zbuf.copy_(z[sh.lo:sh.lo + sh.n])
             if trace is not None:
-                x_before = p.x.clone()
+                x_before = torch.cat([sh.prog.x for sh in self.shards]).clone()
             if graph is not None:
                 graph.replay()
             else:
                 self._step(inject)
             if trace is not None:
-                trace.append((t, x_before, p.eps.clone()))
-        if p.embed_pg is None:   # attribute gathers ran inside the steps: report their range errors now
-            engine.check_err_flag(p.err, "diffusionBackward")
-        return p.x.clone()
+                trace.append((t, x_before, torch.cat([sh.prog.eps for sh in self.shards]).clone()))
+        for sh in self.shards:
+            if sh.prog.embed_pg is None:   # attribute gathers ran inside the steps: report their range errors now
+                engine.check_err_flag(sh.prog.err, "diffusionBackward")
+        return torch.cat([sh.prog.x for sh in self.shards]) if len(self.shards) > 1 else self.prog.x.clone()

@@ -162,9 +162,13 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
 
 def conv_roofline(model, a, dtype_name, dev):
     """Roofline of the dominant kernel (conv GEMM): per-launch HIP-event times of one denoise step, on the launch stream."""
+    from trajectorydiffusion_amd.sampler import auto_shards
     B, L = a.batch, a.L
+    ns = getattr(model, "sampler_slices", None) if not os.environ.get("TDX_SAMPLER_SHARDS") else None
+    ns = auto_shards(B, a.low_latency) if ns is None else ns   # the sampler runs the batch as ns slices on ns streams: a launch = one slice's call
+    B = B // ns
     prog = model.program(B, L // 8 if a.workload == "c5" else L, dev, split_embed=True)
-    prof = prog.pg.profile(repeats=3)
+    prof = prog.pg.profile(repeats=3, inner=4)   # (4 launches per event pair: the event packets' own queue time stays out of the per-launch figure)
     gemm = [(n, ms, fl) for n, fn, ms, fl in prof if fn == "tdx_conv_gemm"]
     gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
     step_ms = sum(ms for _, _, ms, _ in prof)
@@ -174,7 +178,7 @@ def conv_roofline(model, a, dtype_name, dev):
     if src is not None:
         try:
             pm = json.load(open(src))
-            if pm["workload"] == f"B={B}, L={L}, {dtype_name}":
+            if pm["workload"] == f"B={B}, L={L}, {dtype_name}":   # (B = trajectories per launch)
                 traffic = round(pm["conv_gemm_bytes_per_launch_avg"])
         except (OSError, KeyError, ValueError):
             pass
@@ -187,14 +191,16 @@ def conv_roofline(model, a, dtype_name, dev):
         return {"bound": "mfma", "kernel": "tdx_conv_gemm: every Conv1d / nn.Linear / attention projection of one SDUNet_CAR denoise step (%d calls)" % len(gemm),
                 "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4), "traffic": None,
                 "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm), "flop_per_launch_avg": gemm_fl / len(gemm),
-                "flop_per_traj_step": gemm_fl / B, "gemm_ms_per_step": round(gemm_ms, 3), "other_kernels_ms_per_step": others,
-                "all_kernels_ms_per_step": round(step_ms, 3)}
-    return {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call = main grid + optional small-tile tail grid; all %d calls of one denoise step)" % len(gemm),
+                "flop_per_traj_step": gemm_fl / B, "gemm_ms_per_step": round(gemm_ms * ns, 3),
+                "other_kernels_ms_per_step": {k: round(v * ns, 4) for k, v in others.items()}, "all_kernels_ms_per_step": round(step_ms * ns, 3),
+                "trajectories_per_launch": B, "slices_per_step": ns}
+    return {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call on one batch slice of %d trajectories = main grid + optional small-tile tail grid; all %d calls of one slice's denoise step; the sampler runs %d slices per step)" % (B, len(gemm), ns),
             "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4),
             "traffic": traffic, "traffic_source": (os.path.relpath(src, ROOT) + " (rocprofv3 --pmc, bytes per launch, avg over the calls of one step)") if traffic is not None else None,
             "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * es * B / len(gemm)), "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
-            "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms, 3),
-            "other_kernels_ms_per_step": others, "all_kernels_ms_per_step": round(step_ms, 3)}
+            "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms * ns, 3),
+            "other_kernels_ms_per_step": {k: round(v * ns, 4) for k, v in others.items()}, "all_kernels_ms_per_step": round(step_ms * ns, 3),
+            "trajectories_per_launch": B, "slices_per_step": ns}
 
 
 def main(argv=None):

@@ -3,12 +3,15 @@
 `bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph` into profiles/rN_pmc_traffic.json: HBM bytes of the conv
 GEMM kernels per denoise step and per tdx_conv_gemm call (38 calls per step; a call may be two kernel launches).
 
-usage: python scripts/pmc_traffic.py FETCH.csv WRITE.csv OUT.json "B=4096, L=200, bf16"
+usage: python scripts/pmc_traffic.py FETCH.csv WRITE.csv OUT.json "B=2048, L=200, bf16" [slices]
+B = trajectories per launch; slices = batch slices the sampler ran per denoise step (sampler.auto_shards: 2 at B=4096), so a
+denoise step holds 38 x slices tdx_conv_gemm calls and 34 x slices GroupNorm launches.
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts half of wide coalesced reads -> doubled;
 both counters are in KiB.  Calibration: groupnorm_act reads and writes every element exactly once."""
 import csv, json, sys
 fetch_csv, write_csv, out, workload = sys.argv[1:5]
-CALLS_PER_STEP, GN_PER_STEP = 38, 34
+SLICES = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+CALLS_PER_STEP, GN_PER_STEP = 38 * SLICES, 34 * SLICES
 
 
 def load(path, counter):
@@ -36,13 +39,13 @@ B = int(workload.split("B=")[1].split(",")[0])
 es = 2 if "bf16" in workload else 4
 res = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph",
-    "workload": workload, "raw": raw, "denoise_steps_covered": steps,
+    "workload": workload, "slices_per_denoise_step": SLICES, "raw": raw, "denoise_steps_covered": steps,
     "gfx950_correction": "FETCH_SIZE doubled; calibration on groupnorm_act: 2*FETCH = %.2f GB/step, WRITE = %.2f GB/step vs %.2f GB algorithmic each"
-                         % (gn_rd / 1e9, gn_wr / 1e9, 599040 * es * B / 1e9),
+                         % (gn_rd / 1e9, gn_wr / 1e9, 599040 * es * B * SLICES / 1e9),
     "conv_gemm_kernel_launches_per_step": raw["FETCH_SIZE"]["conv_gemm"]["launches"] / steps,
     "conv_gemm_bytes_per_denoise_step": {"read": rd, "write": wr, "total": rd + wr},
     "conv_gemm_bytes_per_launch_avg": (rd + wr) / CALLS_PER_STEP,
-    "conv_gemm_algorithmic_bytes_per_denoise_step": {"read_activations_once": 920976 * es * B, "write": 831376 * es * B,
+    "conv_gemm_algorithmic_bytes_per_denoise_step": {"read_activations_once": 920976 * es * B * SLICES, "write": 831376 * es * B * SLICES,
                                                      "weights": 47.5e6 * es},
 }
 json.dump(res, open(out, "w"), indent=1)

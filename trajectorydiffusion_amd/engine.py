@@ -221,19 +221,22 @@ class Program:
             if rc:
                 _lib.check(rc, name)
 
-    def profile(self, repeats: int = 3):
-        """Per-op device time (ms, best of `repeats`) from HIP events on the launch stream."""
+    def profile(self, repeats: int = 3, inner: int = 1):
+        """Per-op device time (ms, best of `repeats`) from HIP events on the launch stream.  inner > 1 launches every op that many
+        times between its two events and divides: an event record is a packet of its own on the queue, worth several microseconds
+        next to a 50-microsecond kernel (rocprofv3's kernel durations carry no such share)."""
         st = _lib.stream_ptr()
         best = [float("inf")] * len(self.ops)
         for _ in range(repeats):
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.ops) + 1)]
-            evs[0].record()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(len(self.ops))]
             for i, (name, fn, args) in enumerate(self.ops):
-                _lib.check(fn(*args, st), name)
-                evs[i + 1].record()
+                evs[i][0].record()
+                for _ in range(inner):
+                    _lib.check(fn(*args, st), name)
+                evs[i][1].record()
             torch.cuda.synchronize()
             for i in range(len(self.ops)):
-                best[i] = min(best[i], evs[i].elapsed_time(evs[i + 1]))
+                best[i] = min(best[i], evs[i][0].elapsed_time(evs[i][1]) / inner)
         return [(self.ops[i][0], self.ops[i][1].__name__, best[i], self.flops.get(i, 0.0)) for i in range(len(self.ops))]
 
 

@@ -37,6 +37,8 @@ class GraphSampler:
                  shards: Optional[int] = None):
         self.dm, self.model, self.B, self.L, self.device = dm, model, B, L, device
         self.lib = _lib.lib()
+        if shards is None:   # a model may pin its slice count (SDUNet_CAR: its GEMMs at 3-24 rows per trajectory lose more from halving than the overlap returns)
+            shards = getattr(model, "sampler_slices", None) if not os.environ.get("TDX_SAMPLER_SHARDS") else None
         ns = auto_shards(B, getattr(model, "low_latency", False)) if shards is None else int(shards)
         if ns < 1 or B % ns:
             raise TdxError(f"sampler: {ns} shards do not divide a batch of {B}")
@@ -106,8 +108,10 @@ class GraphSampler:
                        "tdx_ddpm_update")
 
     def _step(self, inject: bool) -> None:
-        if len(self.shards) == 1:
-            return self._step_shard(self.shards[0], inject)
+        if len(self.shards) == 1 or os.environ.get("TDX_SAMPLER_SERIAL"):   # (serial: the slices one after the other on one stream, for kernel traces)
+            for sh in self.shards:
+                self._step_shard(sh, inject)
+            return
         cur = torch.cuda.current_stream()
         for sh in self.shards:     # fork: each slice's chain of launches on its own stream (also under graph capture: parallel branches)
             sh.stream.wait_stream(cur)

@@ -321,3 +321,21 @@ def test_c5_full_size_b4096_properties(car, car_sd):
     assert rel(full[idx], ref) < BF16_TOL
     car.set_compute_dtype(torch.float32)
     car._programs.clear()
+
+
+def test_latent_ddim_matches_oracle_loop(car, car_sd):
+    """DDIM (eta = 0, not in the reference: parity unpinned by it) on the latent denoiser, through the same graph-replayed sampler."""
+    from oracle import DiffusionOracle
+    from trajectorydiffusion_amd import DiffusionManager
+    T, n_steps = 40, 4
+    car.cuda().set_compute_dtype(torch.float32)
+    x, _, cat, num = inputs(3, 4, 24, 500, 71)
+    dm = DiffusionManager(0.0001, 0.05, T, device="cuda")
+    got = dm.ddimBackward(x.cuda(), cat.cuda(), num.cuda(), car, n_steps=n_steps)
+    o = DiffusionOracle(0.0001, 0.05, T)
+    ts = torch.linspace(T - 1, 0, n_steps).round().to(torch.int64).tolist()
+    ref = x
+    for i, t in enumerate(ts):
+        e = O.sdunet_car_forward(car_sd, ref, torch.full((3,), t, dtype=torch.long), cat, num, FULL, 500, 4)
+        ref = o.ddim_step(ref, t, ts[i + 1] if i + 1 < len(ts) else -1, e)
+    assert rel(got, ref) < 5e-4

@@ -21,16 +21,38 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const T* __restric
   const int b0 = blockIdx.x * TB;
   const int ntb = min(TB, B - b0);
   const int vpt = 2 * C / VEC;             // 16-byte vectors per token row
-  for (int i = threadIdx.x; i < ntb * N * vpt; i += 256) {
-    const int v = i % vpt, tn = i / vpt;
-    const int n = tn % N, tb = tn / N;
-    *reinterpret_cast<u32x4*>(kvs + ((size_t)tn * 2 * C) + v * VEC) =
-        *reinterpret_cast<const u32x4*>(kv + (size_t)(b0 + tb) * kv_bs + (size_t)n * kv_ld + v * VEC);
+  // staging in batches of 8 vectors per thread: all loads of a batch are in flight before the first LDS store (one load, one wait,
+  // one store per trip would cost a memory round trip per 4 KB of a 28 KB working set)
+  const int nvec = ntb * N * vpt;
+  for (int i0 = threadIdx.x; i0 < nvec; i0 += 256 * 8) {
+    u32x4 held[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 256;
+      const int ic = i < nvec ? i : nvec - 1;
+      const int v = ic % vpt, tn = ic / vpt;
+      const int n = tn % N, tb = tn / N;
+      held[k] = *reinterpret_cast<const u32x4*>(kv + (size_t)(b0 + tb) * kv_bs + (size_t)n * kv_ld + v * VEC);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 256;
+      if (i < nvec) *reinterpret_cast<u32x4*>(kvs + (size_t)i * VEC) = held[k];
+    }
   }
-  __syncthreads();
   const int lpr = C / VEC, lph = lpr >> 3, rpp = 256 / lpr;
   const int col = threadIdx.x % lpr, rip = threadIdx.x / lpr;
   const int rows = ntb * L;
+  // the query vector of a pass is requested one pass ahead (the first one before the K | V staging is waited for): a pass is a
+  // dependent chain load -> 7 dots -> softmax -> 7 fmas -> store, and L = 3 .. 24 rows give a workgroup only 1 .. 3 passes
+  auto q_load = [&](int r0) -> u32x4 {
+    const int r = r0 + rip;
+    const int rc = r < rows ? r : rows - 1;
+    const int tb = rc / L, l = rc - tb * L;
+    return *reinterpret_cast<const u32x4*>(q + ((size_t)(b0 + tb) * L + l) * q_ld + col * VEC);
+  };
+  u32x4 q_next = q_load(0);
+  __syncthreads();
   for (int r0 = 0; r0 < rows; r0 += rpp) {
     const int r = r0 + rip;
     const bool live = r < rows;
@@ -38,7 +60,8 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const T* __restric
     const int tb = rc / L, l = rc - tb * L;
     const size_t grow = (size_t)(b0 + tb) * L + l;
     float qv[VEC];
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(q + grow * q_ld + col * VEC), qv);
+    Elem<T>::unpack(q_next, qv);
+    if (r0 + rpp < rows) q_next = q_load(r0 + rpp);
     const T* kt = kvs + (size_t)tb * N * 2 * C + col * VEC;
     float s[8];
     float m = -3.0e38f;

@@ -339,3 +339,55 @@ def test_latent_ddim_matches_oracle_loop(car, car_sd):
         e = O.sdunet_car_forward(car_sd, ref, torch.full((3,), t, dtype=torch.long), cat, num, FULL, 500, 4)
         ref = o.ddim_step(ref, t, ts[i + 1] if i + 1 < len(ts) else -1, e)
     assert rel(got, ref) < 5e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (3, 8), (2, 15), (5, 200)])
+def test_vae_edge_shapes(vae, B, L):
+    """One trajectory, the shortest length with a non-empty latent (L // 8 == 1), a length that is no multiple of 8, and L = 200."""
+    sd = cpu_sd(vae)
+    vae.cuda()
+    x = torch.randn((B, 2, L), generator=torch.Generator().manual_seed(100 + L))
+    z_ref = O.vae_encode(sd, x)
+    z = vae.encode(x.cuda())
+    assert z.shape == (B, 4, L // 8)
+    assert rel(z, z_ref) < FP32_TOL
+    assert rel(vae.decode(z_ref.cuda()), O.vae_decode(sd, z_ref)) < FP32_TOL
+
+
+def test_vae_rejects_bad_inputs(vae):
+    from trajectorydiffusion_amd._lib import TdxError
+    vae.cuda()
+    with pytest.raises(TdxError):
+        vae.encode(torch.randn(2, 2, 7).cuda())        # L // 8 == 0: the reference's adaptive_avg_pool1d(., 0) fails too
+    with pytest.raises(TdxError):
+        vae.encode(torch.randn(2, 3, 64).cuda())
+    with pytest.raises(TdxError):
+        vae.decode(torch.randn(2, 2, 8).cuda())
+    with pytest.raises(TdxError):
+        vae.encode(torch.randn(2, 2, 64))               # CPU tensor: no fallback
+    vae.train()
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.randn(2, 2, 64).cuda())
+    vae.eval()
+
+
+def test_sdunet_car_single_trajectory_and_odd_batch(car, car_sd):
+    car.cuda().set_compute_dtype(torch.float32)
+    for B in (1, 7):
+        x, t, cat, num = inputs(B, 4, 24, 500, 80 + B)
+        ref = O.sdunet_car_forward(car_sd, x, t, cat, num, FULL, 500, 4)
+        assert rel(car(x.cuda(), t.cuda(), cat.cuda(), num.cuda()), ref) < FP32_TOL
+
+
+def test_sdunet_car_index_errors_are_python_exceptions(car):
+    car.cuda().set_compute_dtype(torch.float32)
+    x, t, cat, num = inputs(2, 4, 24, 500, 90)
+    bad_t = t.clone()
+    bad_t[1] = 500
+    with pytest.raises(IndexError):
+        car(x.cuda(), bad_t.cuda(), cat.cuda(), num.cuda())
+    bad_c = cat.clone()
+    bad_c[0, 2] = 256
+    with pytest.raises(IndexError):
+        car(x.cuda(), t.cuda(), bad_c.cuda(), num.cuda())
+    assert torch.isfinite(car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())).all()   # the flag was cleared: the next call is clean

@@ -17,8 +17,8 @@ for r in csv.DictReader(open(src)):
     acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
     launches[fam] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
 out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT "
-                  "SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph",
-       "workload": "B=4096, L=200, bf16 (6 denoise steps incl. the roofline pass)", "families": {}}
+                  "SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-fp32-leg --no-graph (TDX_SAMPLER_SERIAL=1)",
+       "workload": "B=4096 as 2 slices of 2048 in series, L=200, bf16 (T=3 denoise steps + the roofline pass)", "families": {}}
 for fam, c in acc.items():
     cyc = c["GRBM_GUI_ACTIVE"] / 8
     wc = c["SQ_WAVE_CYCLES"] or 1.0

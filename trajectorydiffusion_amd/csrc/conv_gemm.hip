@@ -1547,257 +1547,6 @@ int dispatch_stream(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win,
   return tc == 256 ? launch_stream<T, 256, 256, false>(a, st, cus) : launch_stream<T, 128, 256, false>(a, st, cus);
 }
 
-// ------------------------------------------------------------------------------------------------------
-// EXPERIMENT (opt-in, tdx_conv_gemm_force_small bit 17): the 256 x 256 window kernel with a THREE-stage weight ring and the
-// barrier in the MIDDLE of the K-step.  The stage of step g + 1 has then landed (and been published by the mid-step barrier of
-// step g) before the MFMAs of step g end, so the first fragments of step g + 1 are requested under the tail of step g and no
-// LDS round trip is exposed after a barrier.  160 KB of LDS exactly: 3 x 32 KB weight stages + 2 x 32 KB windows of 256 rows;
-// the tile has 254 valid rows (window rows n0 - 1 .. n0 + 254) and the zero row of the two-stage kernel is replaced by zeroing
-// padded fragments in registers.  bf16, one stride-1 three-tap segment, no embed rows / residual.  Same K order per output
-// element as the other kernels: bit-identical results.
-__global__ __launch_bounds__(512) void conv_gemm_s3_kernel(const ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  using T = __bf16;
-  constexpr int TC = 256, TR = 256, ES = 2, NW = 8, BK = 64, MI = 8, NI = 4;
-  constexpr int A_BYTES = TC * kRowBytes, W_BYTES = 256 * kRowBytes, W_BASE = 3 * A_BYTES;
-  constexpr int GA = TC / 8 / NW, GW = 256 / 8 / NW;
-  constexpr int TROWS = 254;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
-  const int fr = lane & 15, fq = lane >> 4, r8 = lane >> 3;
-  const uint32_t chunk_off = (uint32_t)(((lane & 7) ^ r8) << 4);
-  const SegDev& sg = p.seg[0];
-
-  const int nco = (p.cout + TC - 1) / TC;
-  const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-  const int jt_end = nco * ((p.row_tiles + 7) >> 3);
-  auto tile_of = [&](int jt, int& n0, int& co0) -> bool {
-    const int rg = jt / nco, row_tile = rg * 8 + xcd;
-    n0 = p.n_begin + row_tile * TROWS;
-    co0 = (jt - rg * nco) * TC;
-    return jt < jt_end && row_tile < p.row_tiles && n0 < p.N;
-  };
-  int jt = blockIdx.x >> 3, cp_n0, cp_co0;
-  if (!tile_of(jt, cp_n0, cp_co0)) return;
-  const int nsteps = p.nsteps, nblk = nsteps / 3;
-
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, 22, false, false, false, false>;   // (bias row read in the epilogue: the K loop has no registers for it)
-  constexpr int PATCH = 2 * 16 * (32 * 4 + 16), NPW = W_BYTES / PATCH;
-
-  // ---- loader cursors: weights run two K-steps ahead of the MFMAs, windows one channel block ahead, both across tiles ----
-  int a_jt = jt, a_s = 0;
-  bool a_ok = true;
-  u32x4 rsrc_a;
-  uint32_t soff_a = 0;
-  const uint32_t voff_a0 = (uint32_t)(8 * wave + r8) * (uint32_t)(p.ktot * ES) + chunk_off;
-  const uint32_t stride_a = (uint32_t)(8 * NW) * (uint32_t)(p.ktot * ES);
-  auto a_tile = [&]() {
-    int n0, co0;
-    a_ok = tile_of(a_jt, n0, co0);
-    if (a_ok) {
-      const int rows_a = p.cout - co0 < TC ? p.cout - co0 : TC;
-      rsrc_a = make_srd(p.w + (size_t)co0 * p.ktot * ES, (uint32_t)rows_a * (uint32_t)p.ktot * ES);
-    }
-    a_s = 0;
-    soff_a = 0;
-  };
-  auto issue_a = [&](int slot) {
-    if (!a_ok) return;
-    const uint32_t a = lds_base + slot * A_BYTES + wave * 1024;
-    const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
-#pragma unroll
-    for (int i = 0; i < GA; ++i) dma16(a + i * NW * 1024, voff_a0 + i * stride_a, rsrc_a, so);
-    soff_a += kRowBytes;
-    if (++a_s >= nsteps) {
-      a_jt += nslot;
-      a_tile();
-    }
-  };
-  int w_jt = jt, w_b = 0;
-  bool w_ok = true;
-  u32x4 rsrc_b;
-  uint32_t voff_w0 = 0, stride_w = 0;
-  auto w_tile = [&]() {
-    int n0, co0;
-    w_ok = tile_of(w_jt, n0, co0);
-    if (w_ok) {
-      const int base_row = n0 - 1 > 0 ? n0 - 1 : 0;
-      const size_t base = ((size_t)base_row * sg.src_ld + sg.ch_off) * ES;
-      const size_t left = (size_t)p.N * sg.src_ld * ES - base;
-      rsrc_b = make_srd(sg.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
-      voff_w0 = (uint32_t)((n0 - 1 - base_row + 8 * wave + EpiT::opaque(r8)) * sg.src_ld * ES) + chunk_off;
-      stride_w = (uint32_t)(8 * NW * sg.src_ld * ES);
-    }
-    w_b = 0;
-  };
-  auto issue_w = [&](int wslot) {
-    if (!w_ok) return;
-    const uint32_t w = lds_base + W_BASE + wslot * W_BYTES + wave * 1024;
-    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(w_b * BK * ES));
-#pragma unroll
-    for (int i = 0; i < GW; ++i) dma16(w + i * NW * 1024, voff_w0 + i * stride_w, rsrc_b, so);
-    if (++w_b >= nblk) {
-      w_jt += nslot;
-      w_tile();
-    }
-  };
-
-  // ---- MFMA state ----------------------------------------------------------------------------------------------------
-  const int a_frag = (wc * (TC / 2) + fr) * kRowBytes;
-  const int sw = fr & 7;
-  f32x4 acc[MI][NI];
-  uint32_t wm3 = 0;
-  auto masks_of = [&](int n0) -> uint32_t {
-    const int fr_o = EpiT::opaque(fr);
-    uint32_t m = 0;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int i_loc = wr * 64 + ni * 16 + fr_o;
-      const int n = n0 + i_loc;
-      const bool row_ok = n < p.N && i_loc < TROWS;
-      const int l = n - fdiv(n, p.div_m, p.div_k) * p.lout;
-      m |= ((row_ok && l > 0 ? 1u : 0u) | (row_ok ? 2u : 0u) | (row_ok && l + 1 < p.lout ? 4u : 0u)) << (ni * 3);
-    }
-    return m;
-  };
-  u32x4 bf[2][NI], af[4];
-  // first fragments of a step: weight rows 0 and 1 of K half 0, the four activation fragments of K half 0
-  auto prefetch = [&](int aslot, int wslot, int tap, uint32_t mask) {
-    const char* a = smem + aslot * A_BYTES;
-    const char* b = smem + W_BASE + wslot * W_BYTES;
-    af[0] = *reinterpret_cast<const u32x4*>(a + a_frag + ((fq ^ sw) << 4));
-    af[1] = *reinterpret_cast<const u32x4*>(a + a_frag + 16 * kRowBytes + ((fq ^ sw) << 4));
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int wrow = wr * 64 + ni * 16 + fr + tap;
-      const bool ok = (mask >> (ni * 3 + tap)) & 1u;
-      const int off = ok ? wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4) : 0;
-      u32x4 v = *reinterpret_cast<const u32x4*>(b + off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-      bf[0][ni] = v;
-    }
-  };
-
-  EpiT epi;
-  int g = 0, blk = 0;   // global K-step / channel-block counters (ring slots g % 3, blk & 1)
-  a_tile();
-  w_tile();
-  issue_w(0);
-  issue_a(0);
-  issue_a(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  wm3 = masks_of(cp_n0);
-  prefetch(0, 0, 0, wm3);
-  for (;;) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the next tile (for the fragments requested under this tile's last step)
-    int nx_n0, nx_co0;
-    const int jn = jt + nslot;
-    const bool more = tile_of(jn, nx_n0, nx_co0);
-    int tap = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      const char* a = smem + (g % 3) * A_BYTES;
-      const char* b = smem + W_BASE + (blk & 1) * W_BYTES;
-      auto a_addr = [&](int t) { return a + a_frag + (t % MI) * 16 * kRowBytes + (((((t / MI) << 2) + fq) ^ sw) << 4); };
-      // K half 0: eight weight rows; the activation fragments of K half 1 are requested under its first four rows
-#pragma unroll
-      for (int t = 0; t < MI; ++t) {
-        af[(t + 2) % 4] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
-        if (t < NI) {
-          const int wrow = wr * 64 + t * 16 + fr + tap;
-          const bool ok = (wm3 >> (t * 3 + tap)) & 1u;
-          const int off = ok ? (wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4)) ^ 64 : 0;
-          u32x4 v = *reinterpret_cast<const u32x4*>(b + off);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-          bf[1][t] = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[t % 4], bf[0][ni], acc[t][ni]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // mid-step: everything issued a step ago has landed; publish it, then reuse the stage / window every wave has left
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // the step after this one: same block (next tap), next block, or the next tile's first step
-      const bool last = s + 1 == nsteps;
-      const int ntap = tap == 2 ? 0 : tap + 1;
-      const int nwslot = (tap == 2 ? blk + 1 : blk) & 1;
-      const uint32_t nmask = last ? (more ? masks_of(nx_n0) : 0u) : wm3;
-      const char* an = smem + ((g + 1) % 3) * A_BYTES;
-      const char* bn = smem + W_BASE + nwslot * W_BYTES;
-#pragma unroll
-      for (int t = MI; t < 2 * MI; ++t) {
-        if (t + 2 < 2 * MI) af[(t + 2) % 4] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
-        else af[(t + 2) % 4] = *reinterpret_cast<const u32x4*>(an + a_frag + (t + 2 - 2 * MI) * 16 * kRowBytes + ((fq ^ sw) << 4));
-        if (t - MI >= 4 && t - MI < 4 + NI) {   // K half 0 of the next step goes into the registers K half 0 of this step has left
-          const int ni = t - MI - 4;
-          const int wrow = wr * 64 + ni * 16 + fr + ntap;
-          const bool ok = (nmask >> (ni * 3 + ntap)) & 1u;
-          const int off = ok ? wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4) : 0;
-          u32x4 v = *reinterpret_cast<const u32x4*>(bn + off);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-          bf[0][ni] = v;   // (bf[0] was last read by the MFMAs of row t = MI - 1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[t % 4], bf[1][ni], acc[t - MI][ni]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t == MI) {   // the DMA issue sits behind the first row of MFMAs after the barrier
-          issue_a((g + 2) % 3);
-          if (tap == 0) issue_w((blk + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      ++g;
-      if (++tap == 3) {
-        tap = 0;
-        ++blk;
-      }
-      if (last) wm3 = nmask;
-    }
-    const uint32_t scr_a = lds_base + ((g - 1) % 3) * A_BYTES;
-    const uint32_t scr_w = lds_base + W_BASE + ((blk - 1) & 1) * W_BYTES;
-    const uint32_t patch = wave < NPW ? scr_w + wave * PATCH : scr_a + (wave - NPW) * PATCH;
-    const uint32_t eb = scr_a + (NW - NPW) * PATCH;
-    epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
-    if (!more) break;
-    jt = jn;
-    cp_n0 = nx_n0;
-    cp_co0 = nx_co0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-
-int launch_s3(const ConvArgs& a, hipStream_t st, int cus) {
-  const int nco = (a.cout + 255) / 256;
-  const int jt_end = nco * ((a.row_tiles + 7) / 8);
-  const int per_xcd = cus / 8;
-  const int nslot = jt_end < per_xcd ? jt_end : per_xcd;
-  const size_t lds = 5 * 32768;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_s3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      TDX_FAIL(TDX_ERR_HIP, "conv_gemm_s3: cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(conv_gemm_s3_kernel, dim3((unsigned)(8 * nslot)), dim3(512), lds, st, a);
-  TDX_CHECK_LAUNCH("conv_gemm_s3_kernel");
-  return TDX_OK;
-}
-int g_s3 = 0;
-
 }  // namespace
 
 // Validate a descriptor, translate it to kernel arguments and choose the kernel.  kind: 0 = register-staged
@@ -1980,12 +1729,6 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
     const int nrc = tdx_narrow_conv_try(d, st, cu_count(), &handled);
     if (nrc != TDX_OK || handled) return nrc;
   }
-  if (g_s3 && ch.kind == 2 && ch.tc == 256 && !ch.gn && d->dtype == TDX_BF16 && d->nseg == 1 && d->seg[0].taps == 3 && !a.res && !a.ebias &&
-      d->seg[0].cin % 64 == 0) {   // experiment: three-stage ring, mid-step barrier (see conv_gemm_s3_kernel)
-    a.tile_rows = 254;
-    a.row_tiles = (a.N + 253) / 254;
-    return launch_s3(a, st, cu_count());
-  }
   if (ch.kind != 0) return d->dtype == TDX_F32 ? run_dma<float>(a, ch, st) : run_dma<__bf16>(a, ch, st);
   // Few tiles and a long K loop (small batches): cut K into slices that run as concurrent workgroups, if the caller gave room.
   const int64_t tiles128 = (int64_t)((a.N + 127) / 128) * ((a.cout + 127) / 128);
@@ -2008,8 +1751,7 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
 //             8 = never use the 128-row (two workgroups per CU) tiles, 16 = no tail split, 32 = one tile per workgroup
 //             (no persistent kernel), 64 = never split K, 128 = 128-channel tiles for every Cout;
 //             bits 8..15, when non-zero: tail-split threshold in units of 2 tiles (ablation);
-//             bit 16 = never take the narrow (128 -> 128, k = 3) kernel of narrow_conv.hip;
-//             bit 17 = EXPERIMENT: the three-stage / mid-step-barrier kernel for plain 256-channel window convs.
+//             bit 16 = never take the narrow (128 -> 128, k = 3) kernel of narrow_conv.hip.
 extern "C" int tdx_conv_gemm_norm_fusable(const tdx_conv_desc* d) {
   ConvArgs a;
   Choice ch;
@@ -2019,7 +1761,6 @@ extern "C" int tdx_conv_gemm_norm_fusable(const tdx_conv_desc* d) {
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   tdx_narrow_conv_disable((bits >> 16) & 1);
   g_force = bits & 0xff;
-  g_s3 = (bits >> 17) & 1;
   g_tail_max = (bits >> 8) & 0xff ? ((bits >> 8) & 0xff) * 2 : 128;
   return TDX_OK;
 }

@@ -979,7 +979,7 @@ struct Epi {
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          const int n = n0 + wr * (NI * 16) + ni * 16 + r0 + RPP * i;
+          const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
           const int co = co0 + wc * WCO + q * PC + c * VEC;
           resv[ni][q][i] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES)
                                                       : (u32x4){0u, 0u, 0u, 0u};
@@ -1084,7 +1084,7 @@ struct Epi {
       if constexpr (EB) if (eb_lds_on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          const int n = n0 + wr * (NI * 16) + ni * 16 + r0 + RPP * i;
+          const int n = n0 + wr * 64 + ni * 16 + r0 + RPP * i;
           int t = fdiv(n < n_end ? n : n_end - 1, p.div_m, p.div_k) - b_first;  // (rows past the end are never stored)
 #pragma unroll
           for (int h = 0; h < VEC / 4; ++h) x.eb[i][h] = lds_ld16(eb_lds + ((1 + t) * TCH + chl + h * 4) * 4);
@@ -1103,7 +1103,7 @@ struct Epi {
       const int chl = wc * WCO + q * PC + c * VEC;  // channel inside the block tile
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        const int row_local = wr * (NI * 16) + ni * 16 + r0 + RPP * i;
+        const int row_local = wr * 64 + ni * 16 + r0 + RPP * i;
         const int n = n0 + row_local;
         const bool live = n < n_end && co0 + chl < p.cout;
         float v[VEC];
@@ -1547,204 +1547,6 @@ int dispatch_stream(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win,
   return tc == 256 ? launch_stream<T, 256, 256, false>(a, st, cus) : launch_stream<T, 128, 256, false>(a, st, cus);
 }
 
-// ------------------------------------------------------------------------------------------------------
-// EXPERIMENT (opt-in, tdx_conv_gemm_force_small bit 17): the 256 x 256 window kernel with FOUR waves of 128 channels x 128 rows
-// (64 accumulator tiles per wave: 256 registers, which at one wave per SIMD come out of the 512-entry file) instead of eight
-// waves of 128 x 64.  One 32 KB weight stage then feeds the same 512 MFMAs per K-step through 128 KB of fragment reads instead
-// of 196 KB.  Same two-stage ring, windows, K order and epilogue as the production kernel: bit-identical results.
-// bf16, one stride-1 three-tap segment, no embed rows / residual.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_w4_kernel(const ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  using T = __bf16;
-  constexpr int TC = 256, TR = 256, ES = 2, NW = 4, BK = 64, MI = 8, NI = 8;
-  constexpr int kWinGroups = win_groups(TR), kWinBytes = win_bytes(TR);
-  constexpr int A_BYTES = TC * kRowBytes, W_BASE = 2 * A_BYTES;
-  constexpr int GA = TC / 8 / NW, GW = (kWinGroups + NW - 1) / NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
-  const int fr = lane & 15, fq = lane >> 4, r8 = lane >> 3;
-  const uint32_t chunk_off = (uint32_t)(((lane & 7) ^ r8) << 4);
-  const SegDev& sg = p.seg[0];
-
-  const int nco = (p.cout + TC - 1) / TC;
-  const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-  const int jt_end = nco * ((p.row_tiles + 7) >> 3);
-  auto tile_of = [&](int jt, int& n0, int& co0) -> bool {
-    const int rg = jt / nco, row_tile = rg * 8 + xcd;
-    n0 = p.n_begin + row_tile * p.tile_rows;
-    co0 = (jt - rg * nco) * TC;
-    return jt < jt_end && row_tile < p.row_tiles && n0 < p.N;
-  };
-  int jt = blockIdx.x >> 3, cp_n0, cp_co0;
-  if (!tile_of(jt, cp_n0, cp_co0)) return;
-  const int nsteps = p.nsteps, nblk = nsteps / 3;
-  using EpiT = Epi<T, NI, TC / 2, TC, NW, 22, false, false, false, false>;
-  constexpr int PATCH = 2 * 16 * (32 * 4 + 16);
-
-  // ---- loader: weights one K-step ahead, windows one channel block ahead, across tiles ------------------------------------
-  int a_jt = jt, a_s = 0;
-  bool a_ok = true;
-  u32x4 rsrc_a;
-  uint32_t soff_a = 0;
-  const uint32_t voff_a0 = (uint32_t)(8 * wave + r8) * (uint32_t)(p.ktot * ES) + chunk_off;
-  const uint32_t stride_a = (uint32_t)(8 * NW) * (uint32_t)(p.ktot * ES);
-  auto a_tile = [&]() {
-    int n0, co0;
-    a_ok = tile_of(a_jt, n0, co0);
-    if (a_ok) {
-      const int rows_a = p.cout - co0 < TC ? p.cout - co0 : TC;
-      rsrc_a = make_srd(p.w + (size_t)co0 * p.ktot * ES, (uint32_t)rows_a * (uint32_t)p.ktot * ES);
-    }
-    a_s = 0;
-    soff_a = 0;
-  };
-  auto issue_a = [&](int slot) {
-    if (!a_ok) return;
-    const uint32_t a = lds_base + slot * A_BYTES + wave * 1024;
-    const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
-#pragma unroll
-    for (int i = 0; i < GA; ++i) dma16(a + i * NW * 1024, voff_a0 + i * stride_a, rsrc_a, so);
-    soff_a += kRowBytes;
-    if (++a_s >= nsteps) {
-      a_jt += nslot;
-      a_tile();
-    }
-  };
-  int w_jt = jt, w_b = 0;
-  bool w_ok = true;
-  u32x4 rsrc_b;
-  uint32_t voff_w0 = 0, stride_w = 0;
-  auto w_tile = [&]() {
-    int n0, co0;
-    w_ok = tile_of(w_jt, n0, co0);
-    if (w_ok) {
-      const int base_row = n0 - 1 > 0 ? n0 - 1 : 0;
-      const size_t base = ((size_t)base_row * sg.src_ld + sg.ch_off) * ES;
-      const size_t left = (size_t)p.N * sg.src_ld * ES - base;
-      rsrc_b = make_srd(sg.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
-      voff_w0 = (uint32_t)((n0 - 1 - base_row + 8 * wave + EpiT::opaque(r8)) * sg.src_ld * ES) + chunk_off;
-      stride_w = (uint32_t)(8 * NW * sg.src_ld * ES);
-    }
-    w_b = 0;
-  };
-  auto issue_w = [&](int wslot) {
-    if (!w_ok) return;
-    const uint32_t w = lds_base + W_BASE + wslot * kWinBytes + wave * 1024;
-    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(w_b * BK * ES));
-#pragma unroll
-    for (int i = 0; i < GW; ++i)
-      if (wave + NW * i < kWinGroups) dma16(w + i * NW * 1024, voff_w0 + i * stride_w, rsrc_b, so);
-    if (++w_b >= nblk) {
-      w_jt += nslot;
-      w_tile();
-    }
-  };
-
-  const int a_frag = (wc * (TC / 2) + fr) * kRowBytes;
-  const int sw = fr & 7;
-  f32x4 acc[MI][NI];
-  uint32_t wm3 = 0;
-  auto masks_of = [&](int n0) -> uint32_t {
-    const int fr_o = EpiT::opaque(fr);
-    uint32_t m = 0;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int i_loc = wr * 128 + ni * 16 + fr_o;
-      const int n = n0 + i_loc;
-      const bool row_ok = n < p.N && i_loc < p.tile_rows;
-      const int l = n - fdiv(n, p.div_m, p.div_k) * p.lout;
-      m |= ((row_ok && l > 0 ? 1u : 0u) | (row_ok ? 2u : 0u) | (row_ok && l + 1 < p.lout ? 4u : 0u)) << (ni * 3);
-    }
-    return m;
-  };
-  if (tid < 16)  // the two zero rows
-    *reinterpret_cast<u32x4*>(smem + W_BASE + (tid >> 3) * kWinBytes + kWinGroups * 8 * kRowBytes + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
-
-  EpiT epi;
-  int g = 0, blk = 0;
-  a_tile();
-  w_tile();
-  issue_w(0);
-  issue_a(0);
-  for (;;) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    wm3 = masks_of(cp_n0);
-    int tap = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const char* a = smem + (g & 1) * A_BYTES;
-      const char* b = smem + W_BASE + (blk & 1) * kWinBytes;
-      int boff[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int wrow = wr * 128 + ni * 16 + fr + tap;
-        boff[ni] = ((wm3 >> (ni * 3 + tap)) & 1u) ? wrow * kRowBytes + ((fq ^ (wrow & 7)) << 4) : kWinGroups * 8 * kRowBytes;
-      }
-      auto a_addr = [&](int t) { return a + a_frag + (t % MI) * 16 * kRowBytes + (((((t / MI) << 2) + fq) ^ sw) << 4); };
-      u32x4 bf[2][NI], af[3];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const u32x4*>(b + boff[ni]);
-      af[0] = *reinterpret_cast<const u32x4*>(a_addr(0));
-      af[1] = *reinterpret_cast<const u32x4*>(a_addr(1));
-#pragma unroll
-      for (int t = 0; t < 2 * MI; ++t) {
-        if (t == 1) {   // the step's DMA issue sits behind the first row of MFMAs
-          issue_a((g + 1) & 1);
-          if (tap == 0) issue_w((blk + 1) & 1);
-        }
-        if (t + 2 < 2 * MI) af[(t + 2) % 3] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
-        if (t < NI) bf[1][t] = *reinterpret_cast<const u32x4*>(b + (boff[t] ^ 64));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(af[t % 3], bf[t / MI][ni], acc[t % MI][ni]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      ++g;
-      if (++tap == 3) {
-        tap = 0;
-        ++blk;
-      }
-    }
-    int nx_n0, nx_co0;
-    const int jn = jt + nslot;
-    const bool more = tile_of(jn, nx_n0, nx_co0);
-    const uint32_t scr_a = lds_base + ((g - 1) & 1) * A_BYTES;
-    const uint32_t scr_w = lds_base + W_BASE + ((blk - 1) & 1) * kWinBytes;
-    epi.finish(p, acc, scr_w + wave * PATCH, scr_a, wave, wr, wc, lane, cp_n0, cp_co0);
-    if (!more) break;
-    jt = jn;
-    cp_n0 = nx_n0;
-    cp_co0 = nx_co0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-
-int launch_w4(const ConvArgs& a, hipStream_t st, int cus) {
-  const int nco = (a.cout + 255) / 256;
-  const int jt_end = nco * ((a.row_tiles + 7) / 8);
-  const int per_xcd = cus / 8;
-  const int nslot = jt_end < per_xcd ? jt_end : per_xcd;
-  const size_t lds = dma_lds_bytes(256, 256, true);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      TDX_FAIL(TDX_ERR_HIP, "conv_gemm_w4: cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(conv_gemm_w4_kernel, dim3((unsigned)(8 * nslot)), dim3(256), lds, st, a);
-  TDX_CHECK_LAUNCH("conv_gemm_w4_kernel");
-  return TDX_OK;
-}
-int g_w4 = 0;
-
 }  // namespace
 
 // Validate a descriptor, translate it to kernel arguments and choose the kernel.  kind: 0 = register-staged
@@ -1927,9 +1729,6 @@ extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {
     const int nrc = tdx_narrow_conv_try(d, st, cu_count(), &handled);
     if (nrc != TDX_OK || handled) return nrc;
   }
-  if (g_w4 && ch.kind == 2 && ch.tc == 256 && !ch.gn && d->dtype == TDX_BF16 && d->nseg == 1 && d->seg[0].taps == 3 && !a.res && !a.ebias &&
-      d->seg[0].cin % 64 == 0)   // experiment: four waves of 128 x 128 (see conv_gemm_w4_kernel)
-    return launch_w4(a, st, cu_count());
   if (ch.kind != 0) return d->dtype == TDX_F32 ? run_dma<float>(a, ch, st) : run_dma<__bf16>(a, ch, st);
   // Few tiles and a long K loop (small batches): cut K into slices that run as concurrent workgroups, if the caller gave room.
   const int64_t tiles128 = (int64_t)((a.N + 127) / 128) * ((a.cout + 127) / 128);
@@ -1962,7 +1761,6 @@ extern "C" int tdx_conv_gemm_norm_fusable(const tdx_conv_desc* d) {
 extern "C" int tdx_conv_gemm_force_small(int32_t bits) {
   tdx_narrow_conv_disable((bits >> 16) & 1);
   g_force = bits & 0xff;
-  g_w4 = (bits >> 17) & 1;
   g_tail_max = (bits >> 8) & 0xff ? ((bits >> 8) & 0xff) * 2 : 128;
   return TDX_OK;
 }

@@ -57,6 +57,9 @@ struct ConvArgs {
   int32_t ksplit, steps_per_split;
 };
 
+#ifndef TDX_SPREAD_DMA
+#define TDX_SPREAD_DMA 1
+#endif
 int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
 int g_tail_max = 128;  // largest remainder (in 256-row tiles) handed to the small-tile tail launch
 int g_debug = 0;
@@ -1163,6 +1166,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   constexpr int A_BYTES = TC * kRowBytes, B_BYTES = TR * kRowBytes;
   constexpr int A_STAGE = WIN ? A_BYTES : A_BYTES + B_BYTES;
   constexpr int W_BASE = 2 * A_BYTES;
+  constexpr bool SPREAD = TDX_SPREAD_DMA && WIN && TC == 256;   // (same-box A/B: +1..4 % on the 256-channel tiles, -1.5 % on the 128-channel ones)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -1208,6 +1212,13 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
 #pragma unroll
     for (int i = 0; i < GA; ++i) dma16(a + i * NW * 1024, voff_a0 + i * stride_a, rsrc_a, so);
     soff_a += kRowBytes;
+  };
+  // the same stage, one DMA per call (spread over the MFMA rows of a K-step); the last piece advances the K offset
+  auto issue_a_piece = [&](int buf, int i) {
+    const uint32_t a = lds_base + buf * A_STAGE + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff_a);
+    dma16(a + i * NW * 1024, voff_a0 + i * stride_a, rsrc_a, so);
+    if (i == GA - 1) soff_a += kRowBytes;
   };
   auto ld_setup = [&]() {  // per segment
     const SegDev& s = p.seg[ld_seg];
@@ -1270,6 +1281,20 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     });
     if (++ld_tap >= ld_taps) {
       ld_tap = 0;
+      ld_ci += BK;
+      if (ld_ci >= ld_cin) {
+        ld_ci = 0;
+        ++ld_seg;
+        if (ld_seg < p.nseg) ld_setup();
+      }
+    }
+  };
+  // one window DMA per call (i = 0 .. GW - 1); the last piece moves the loader on to the next channel block
+  auto issue_window_piece = [&](int wbuf, int i) {
+    const uint32_t w = lds_base + W_BASE + wbuf * kWinBytes + wave * 1024;
+    const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)ld_ci * ES);
+    if (wave + NW * i < kWinGroups) dma16(w + i * NW * 1024, voff_w0 + i * stride_w, rsrc_b, so);
+    if (i == GW - 1) {
       ld_ci += BK;
       if (ld_ci >= ld_cin) {
         ld_ci = 0;
@@ -1350,7 +1375,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     for (int t = 0; t < NT2; ++t) {
       // The step's DMA issue sits behind the first row of MFMAs: right after the barrier the MFMA pipe is empty, and
       // the DMA instructions (m0 set-up, s_nop, issue) would keep it empty for their whole issue time.
-      if (t == 1) mid();
+      mid(t);
       if (t + 2 < NT2) af[(t + 2) % 3] = *reinterpret_cast<const u32x4*>(a_addr(t + 2));
       if (t < NI) bf[1][t] = *reinterpret_cast<const u32x4*>(b + (boff[t] ^ 64));  // second K half, one fragment per row of the first
       __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs of this row (the scheduler would sink them to their uses)
@@ -1391,12 +1416,33 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     __syncthreads();
     const int g_now = g, blk_now = blk, tap_now = cp_tap;
     pend_w = 0;
-    compute(g & 1, blk & 1, [&]() {
+    const bool win_go = WIN && tap_now == 0 && ld_seg < p.nseg;   // (ld_seg moves on only with the window's last piece)
+    compute(g & 1, blk & 1, [&](int t) {
+      // The step's DMA issue sits behind the first row of MFMAs, and (SPREAD) the weight stage goes out one DMA per MFMA row:
+      // a burst of DMA returns into the LDS delays the just-in-time fragment reads of both waves of a SIMD at once.
+      if constexpr (SPREAD && !LAST) {
+        if (t >= 1 && t <= GA) issue_a_piece((g_now + 1) & 1, t - 1);
+      }
+      if constexpr (SPREAD) {   // window pieces behind the weight pieces, the rest of them with the last MFMA row
+        constexpr int NT2 = 2 * MI;
+        if (t > GA && win_go) {
+          const int i0 = t - GA - 1;
+          if (t < NT2 - 1) {
+            if (i0 < GW) issue_window_piece((blk_now + 1) & 1, i0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < GW; ++i)
+              if (i >= i0) issue_window_piece((blk_now + 1) & 1, i);
+          }
+          if (i0 == 0) pend_w = win_dmas;
+        }
+      }
+      if (t != (SPREAD ? GA + 1 : 1)) return;
       if constexpr (!LAST) {
-        issue_a((g_now + 1) & 1);
+        if constexpr (!SPREAD) issue_a((g_now + 1) & 1);
         if constexpr (!WIN) issue_b_gather((g_now + 1) & 1);
       }
-      if constexpr (WIN) {
+      if constexpr (WIN && !SPREAD) {
         if (tap_now == 0 && ld_seg < p.nseg) {
           issue_window((blk_now + 1) & 1);
           pend_w = win_dmas;

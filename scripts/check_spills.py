@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "trajectorydiffusion_amd", "csrc", "conv_gemm.hip")
 out = os.path.join(tempfile.gettempdir(), "conv_gemm_gfx950.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
-                       "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+                       "--cuda-device-only", "-o", out, src] + os.environ.get("TDX_EXTRA_FLAGS", "").split(), stderr=subprocess.DEVNULL)
 name, depth, bad, total = None, 0, {}, {}
 for line in open(out):
     m = re.match(r"^(_Z\w*conv_gemm_stream_kernel\w*):", line)

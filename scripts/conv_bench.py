@@ -26,7 +26,8 @@ B = a.batch
 SHAPES = [  # (name, L, Cin, Cout, taps)
     ("128->128@200", 200, 128, 128, 3), ("256->256@100", 100, 256, 256, 3), ("512->512@50", 50, 512, 512, 3),
     ("1024->1024@25", 25, 1024, 1024, 3), ("1024->1024@13", 13, 1024, 1024, 3), ("2048->512@13", 13, 2048, 512, 3),
-    ("qkv 1024->3072@13", 13, 1024, 3072, 1),
+    ("qkv 1024->3072@13", 13, 1024, 3072, 1), ("128->256@100", 100, 128, 256, 3), ("256->512@50", 50, 256, 512, 3),
+    ("512->1024@25", 25, 512, 1024, 3), ("1x1 1024->1024@13", 13, 1024, 1024, 1),
 ]
 lib = _lib.lib()
 forces = a.force if a.force is not None else [1 if a.small else 0]

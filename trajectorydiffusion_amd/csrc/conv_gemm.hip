@@ -55,10 +55,25 @@ struct ConvArgs {
   // split-K (register-staged kernel only): blockIdx.y = slice z computes K-steps [z * steps_per_split, ...) into partial[z][n][co]
   float* partial;
   int32_t ksplit, steps_per_split;
+#if TDX_STAMPS
+  uint32_t* stamps;
+#endif
 };
+#if TDX_STAMPS
+uint32_t* g_stamps = nullptr;
+#endif
 
 #ifndef TDX_SPREAD_DMA
 #define TDX_SPREAD_DMA 1
+#endif
+#ifndef TDX_DIRECT_EPI
+#define TDX_DIRECT_EPI 1
+#endif
+#ifndef TDX_STAMPS  // diagnostic build: per-phase cycle counts of wave 0 of every workgroup of the stream kernel (scripts/conv_stamps.py)
+#define TDX_STAMPS 0
+#endif
+#ifndef TDX_ABL   // timing ablations of the direct epilogue (never in a product build): 1 = no epilogue, 2 = no stores, 4 = no staged rows
+#define TDX_ABL 0
 #endif
 int g_force = 0;  // test hook, see tdx_conv_gemm_force_small
 int g_tail_max = 128;  // largest remainder (in 256-row tiles) handed to the small-tile tail launch
@@ -946,11 +961,12 @@ struct StreamCfg {
 //   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
 //     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
 //     residual of 256-channel tiles (no registers to hold it during the K loop).
-template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_ROWS, bool PRE_RES, bool RES, bool EB>
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_ROWS, bool PRE_RES, bool RES, bool EB, bool DIRECT_>
 struct Epi {
   // PRE_ROWS: the rows that get staged in LDS are read with the tile's first K-step (else in finish()); PRE_RES: so is the
   // residual.  Both are a question of register room in the K loop (scripts/check_spills.py).
   static constexpr bool PRE = PRE_ROWS;
+  static constexpr bool DIRECT = DIRECT_;
   static constexpr int ES = (int)sizeof(T);
   static constexpr int VEC = 16 / ES;
   static constexpr int PC = 32, NQ = WCO / PC;  // channels per transposed piece, pieces per sub-tile row
@@ -975,6 +991,19 @@ struct Epi {
   }
 
   __device__ __forceinline__ void load_res(const ConvArgs& p, int wr, int wc, int lane, int n0, int co0) {
+    if constexpr (DIRECT) {  // the layout of finish_direct: lane (fr, fq), sub-tile row ni, channel chunk P
+      const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int P = 0; P < NQ * NP; ++P) {
+          const int n = n0 + wr * 64 + ni * 16 + fr;
+          const int co = co0 + wc * WCO + P * 4 * VEC + fq * VEC;
+          resv[ni][P / NP][P % NP] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES)
+                                                                : (u32x4){0u, 0u, 0u, 0u};
+        }
+      return;
+    }
     const int c = lane % CPR, r0 = lane / CPR;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1034,11 +1063,139 @@ struct Epi {
           for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(resv[ni][q][i]));
   }
 
+  // Direct epilogue.  The stream kernel DMAs the weight rows of a wave tile in a permuted order (perm_row below), so that the
+  // accumulators a lane holds for TP = VEC / 4 adjacent 16-channel sub-tiles are VEC CONSECUTIVE output channels of one row:
+  // 16 bytes per lane straight from the registers, 64-byte row segments per store instruction (what the transposing epilogue
+  // stores too), and no LDS round trip for the values.  LDS holds only the staged bias / embed rows.  Same association of the
+  // additions as finish(): (acc + (bias + step row)) + trajectory row -> act -> + residual.
+  //   sub-tile mi, MFMA row m (lane group fq = m >> 2, register j = m & 3)  ->  channel (mi / TP) * 16 * TP + fq * VEC + (mi % TP) * 4 + j
+  static __device__ __forceinline__ int perm_row(int x) {  // x = LDS row of the weight stage; returns the weight row that goes there
+    if constexpr (VEC == 8) return (x & ~0x1c) | ((x & 0x08) << 1) | ((x & 0x04) << 1) | ((x & 0x10) >> 2);
+    else return x;
+  }
+  // bias + time-step row and the tile's per-trajectory embed rows: registers (prefetch) -> LDS
+  __device__ __forceinline__ void stage_rows(uint32_t eb_lds, int wave, int lane_) {
+    const int tid_e = wave * 64 + opaque(lane_);
+#pragma unroll
+    for (int k = 0; k < EBR; ++k) {
+      const int idx = tid_e + k * NT;
+      if (idx < (1 + (eb_staged ? ntraj : 0)) * (TCH / 4)) lds_st16(eb_lds + idx * 16, ebv[k]);
+    }
+  }
+  template <int MI>
+  __device__ __forceinline__ void finish_direct(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t eb_lds, int wave, int wr, int wc, int lane_,
+                                                int n0, int co0) {
+    constexpr int TP = VEC / 4, NPR = MI / TP;  // sub-tiles per 16-byte store, stores per sub-tile row
+    static_assert(NPR == NQ * NP && NST == NI * NPR, "store count");
+    const int lane = opaque(lane_);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cw = co0 + wc * WCO;  // first channel of this wave's tile
+    if constexpr (!PRE) prefetch(p, wave, wr, wc, lane, n0, co0);
+    if constexpr (!PRE_RES && RES) load_res(p, wr, wc, lane, n0, co0);
+    const size_t obase = ((size_t)n0 * p.out_ld + p.out_off + cw) * ES;
+    const size_t oleft = (size_t)p.N * p.out_ld * ES - obase;
+    const u32x4 rsrc_o = make_srd(p.out + obase, oleft > 0x7fffffffull ? 0x7fffffffu : (uint32_t)oleft);
+    if constexpr ((TDX_ABL & 1) != 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+      return;
+    }
+    if constexpr ((TDX_ABL & 4) == 0) {
+      __syncthreads();  // every wave is done with the K loop's last buffers: the staged rows go there
+      stage_rows(eb_lds, wave, lane);
+      __syncthreads();
+    }
+    const bool eb_lds_on = (TDX_ABL & 4) == 0 && EB && p.ebias && eb_staged;
+    const int ch0 = wc * WCO + fq * VEC;  // this lane's first channel inside the block tile (chunk P adds P * 4 * VEC)
+    // Items k = ni * NPR + P; the LDS reads of item k + 1 (bias vector, embed row of the row's trajectory) are requested
+    // before the arithmetic of item k.
+    struct Item {
+      f32x4 bs[TP], eb[TP];
+    };
+    uint32_t eb_row = 0;  // LDS address of the staged embed row of sub-tile row ni's trajectory (+ this lane's channel offset)
+    auto get = [&](int k, Item& x) {
+      const int ni = k / NPR, P = k % NPR;
+#pragma unroll
+      for (int h = 0; h < TP; ++h) x.bs[h] = (TDX_ABL & 4) ? (f32x4){0.f, 0.f, 0.f, 0.f} : lds_ld16(eb_lds + (ch0 + P * 4 * VEC + h * 4) * 4);
+      if constexpr (EB) if (eb_lds_on) {
+        if (P == 0) {
+          const int n = n0 + wr * 64 + ni * 16 + fr;
+          const int t = fdiv(n < n_end ? n : n_end - 1, p.div_m, p.div_k) - b_first;  // (rows past the end are never stored)
+          eb_row = eb_lds + ((1 + t) * TCH + ch0) * 4;
+        }
+#pragma unroll
+        for (int h = 0; h < TP; ++h) x.eb[h] = lds_ld16(eb_row + (P * 4 * VEC + h * 4) * 4);
+      }
+    };
+    Item cur, nxt;
+    get(0, cur);
+#pragma unroll
+    for (int k = 0; k < NI * NPR; ++k) {
+      const int ni = k / NPR, P = k % NPR;
+      if (k + 1 < NI * NPR) get(k + 1, nxt);
+      const int row_local = wr * 64 + ni * 16 + fr;
+      const int n = n0 + row_local;
+      const int chl = ch0 + P * 4 * VEC;
+      const bool live = n < n_end && co0 + chl < p.cout;
+      float v[VEC];
+#pragma unroll
+      for (int h = 0; h < TP; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[h * 4 + j] = acc[P * TP + h][ni][j] + cur.bs[h][j];
+      if constexpr (EB) {
+        if (eb_lds_on) {
+#pragma unroll
+          for (int h = 0; h < TP; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[h * 4 + j] += cur.eb[h][j];
+        } else if (p.ebias && live) {  // more trajectories in the tile than staged rows: read the rows from global memory
+          const int bb = fdiv(n, p.div_m, p.div_k);
+          const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co0 + chl;
+#pragma unroll
+          for (int h = 0; h < TP; ++h) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+          }
+        }
+      }
+      if (p.act == TDX_ACT_SWISH) {  // one wave-uniform branch per vector, not one per element
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = tdx_swish(v[j]);
+      } else if (p.act == TDX_ACT_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = tdx_leaky(v[j]);
+      }
+      if constexpr (RES) {
+        float rv[VEC];
+        Elem<T>::unpack(resv[ni][P / NP][P % NP], rv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] += rv[j];
+      }
+      uint32_t voff = live ? (uint32_t)(row_local * p.out_ld + P * 4 * VEC + fq * VEC) * ES : kOob;
+      if constexpr ((TDX_ABL & 8) != 0)  // timing only (wrong data): every store instruction writes 8 rows x 128 contiguous bytes
+        voff = live ? (uint32_t)((wr * 64 + ni * 16 + (fr & 7) + 8 * (P & 1)) * p.out_ld + (P >> 1) * 8 * VEC + ((fr >> 3) * 4 + fq) * VEC) * ES : kOob;
+      if constexpr ((TDX_ABL & 2) != 0) {
+        const u32x4 o = Elem<T>::pack(v);
+        asm volatile("" ::"v"(o), "v"(voff), "s"(rsrc_o));
+      } else {
+        buf_store16(Elem<T>::pack(v), voff, rsrc_o);
+      }
+      cur = nxt;
+    }
+  }
+
   // patch: LDS address of this wave's two pieces; eb_lds: LDS address of the staged rows.
   template <int MI>
   __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t patch, uint32_t eb_lds, int wave, int wr, int wc,
                                          int lane_, int n0, int co0) {
     static_assert(TCH / 4 <= NT, "one staging slot must cover a whole row");
+    if constexpr (DIRECT) {
+      finish_direct(p, acc, eb_lds, wave, wr, wc, lane_, n0, co0);
+      return;
+    }
     const int lane = opaque(lane_);
     const int fr = lane & 15, fq = lane >> 4;
     const int c = lane % CPR, r0 = lane / CPR;
@@ -1192,13 +1349,15 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   int jt = blockIdx.x >> 3, cp_n0, cp_co0;
   if (!tile_of(jt, cp_n0, cp_co0)) return;
 
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128 || WIN, TC == 128, RES, EB>;
+  // (the gathered 256-channel tiles keep the transposing epilogue: no register room for the direct one, scripts/check_spills.py)
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128 || WIN, TC == 128, RES, EB, TDX_DIRECT_EPI && (WIN || TC == 128)>;
   // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
   int ld_n0 = 0;
   u32x4 rsrc_a, rsrc_b;
   // per-lane DMA offsets are kept as ONE base VGPR plus a wave-uniform stride per 8-row group (registers are the
   // scarce resource of this kernel): rows past the end of a buffer fall out of the descriptor's range by themselves
-  const uint32_t voff_a0 = (uint32_t)(8 * wave + r8) * (uint32_t)(p.ktot * ES) + chunk_off;
+  // (direct epilogue: LDS row x of a weight stage holds weight row perm_row(x), see Epi::finish_direct)
+  const uint32_t voff_a0 = (uint32_t)(EpiT::DIRECT ? EpiT::perm_row(8 * wave + r8) : 8 * wave + r8) * (uint32_t)(p.ktot * ES) + chunk_off;
   const uint32_t stride_a = (uint32_t)(8 * NW) * (uint32_t)(p.ktot * ES);
   uint32_t soff_a = 0;
   int ld_seg = 0, ld_ci = 0, ld_tap = 0, ld_taps = 1, ld_cin = 0;
@@ -1225,6 +1384,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     ld_taps = s.taps;
     ld_cin = s.cin;
     const int pad = s.taps == 3 ? 1 : 0;
+    // (recomputed from the lane index here, once per segment, rather than kept in a register across the K loop)
+    const int lane_o = EpiT::opaque(lane);
+    const uint32_t chunk_off = (uint32_t)(((lane_o & 7) ^ (lane_o >> 3)) << 4);
     if constexpr (WIN) {
       const int base_row = ld_n0 - pad > 0 ? ld_n0 - pad : 0;
       const size_t base = ((size_t)base_row * s.src_ld + s.ch_off) * ES;
@@ -1393,6 +1555,14 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   // ---- the pipeline: g counts K-steps over all tiles (weight stage g & 1), blk counts channel blocks (window blk & 1) ----
   static_assert(EpiT::NST == Cfg::NST, "store count must match StreamCfg::NST");
   EpiT epi;
+#if TDX_STAMPS
+  const uint32_t st_base = lds_base + (uint32_t)(WIN ? W_BASE + 2 * kWinBytes : 2 * A_STAGE);
+  if (tid < 16) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(st_base + tid * 4) = 0u;
+  auto st_now = [&]() -> uint32_t { return (uint32_t)__builtin_amdgcn_s_memtime(); };
+  auto st_add = [&](int k, uint32_t d) {
+    if (tid == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(st_base + k * 4) += d;
+  };
+#endif
   int g = 0, blk = 0;
   bool counted = false;  // the previous tile's epilogue stores are this wave's youngest vector-memory operations
   loader_begin(cp_n0, cp_co0);
@@ -1410,10 +1580,19 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   };
   auto step = [&](auto first_c, auto last_c) {
     constexpr bool FIRST = decltype(first_c)::value != 0, LAST = decltype(last_c)::value != 0;
+#if TDX_STAMPS
+    const uint32_t st0 = st_now();
+#endif
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
     else wait_vm(cp_tap == 0 ? 0 : pend_w);  // (a block's first step needs its window)
     counted = false;
+#if TDX_STAMPS
+    const uint32_t st1 = st_now();
+#endif
     __syncthreads();
+#if TDX_STAMPS
+    const uint32_t st2 = st_now();
+#endif
     const int g_now = g, blk_now = blk, tap_now = cp_tap;
     pend_w = 0;
     const bool win_go = WIN && tap_now == 0 && ld_seg < p.nseg;   // (ld_seg moves on only with the window's last piece)
@@ -1443,7 +1622,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
         if constexpr (!WIN) issue_b_gather((g_now + 1) & 1);
       }
       if constexpr (WIN && !SPREAD) {
-        if (tap_now == 0 && ld_seg < p.nseg) {
+        if (win_go) {
           issue_window((blk_now + 1) & 1);
           pend_w = win_dmas;
         }
@@ -1451,6 +1630,15 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       // the epilogue's global reads go out with the tile's FIRST K-step: they land under the rest of the K loop
       if constexpr (FIRST && EpiT::PRE) epi.prefetch(p, wave, wr, wc, lane, cp_n0, cp_co0);
     });
+#if TDX_STAMPS
+    {
+      const uint32_t st3 = st_now();
+      constexpr int SB = FIRST ? 0 : 6;
+      st_add(SB, st1 - st0);
+      st_add(SB + 1, st2 - st1);
+      st_add(SB + 2, st3 - st2);
+    }
+#endif
     ++g;
     if (++cp_tap >= cp_taps) {
       cp_tap = 0;
@@ -1477,6 +1665,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       for (int s = 0; s + 1 < p.nsteps; ++s) step(TapC<0>{}, TapC<0>{});
       step(TapC<0>{}, TapC<1>{});
     }
+#if TDX_STAMPS
+    const uint32_t sb0 = st_now();
+#endif
     if constexpr (EpiT::PRE) epi.pin(p);
     // tile boundary: the loader goes ahead, then the epilogue runs in the buffers the last K-step released
     int nx_n0, nx_co0;
@@ -1498,13 +1689,27 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       patch = scr_a + wave * Cfg::PATCH;
       eb = scr_a + NW * Cfg::PATCH;
     }
+#if TDX_STAMPS
+    const uint32_t sb1 = st_now();
+#endif
     epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
-    counted = true;
+#if TDX_STAMPS
+    {
+      const uint32_t sb2 = st_now();
+      st_add(9, sb1 - sb0);
+      st_add(11, sb2 - sb1);
+      st_add(15, 1u);
+    }
+#endif
+    counted = !(EpiT::DIRECT && (TDX_ABL & 3) != 0);
     if (!more) break;
     jt = jn;
     cp_n0 = nx_n0;
     cp_co0 = nx_co0;
   }
+#if TDX_STAMPS
+  if (p.stamps && tid < 16) p.stamps[blockIdx.x * 16 + tid] = *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(st_base + tid * 4);
+#endif
 #endif
 }
 
@@ -1552,6 +1757,7 @@ int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   const int per_xcd = (cus / 8) * (TR == 128 ? 2 : 1);  // resident workgroups per XCD
   const int nslot = jt_end < per_xcd ? jt_end : per_xcd;
   size_t lds = dma_lds_bytes(TC, TR, WIN);
+  if (TDX_STAMPS) lds += 64;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, MODE>),
@@ -1655,6 +1861,9 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   a.B = d->B;
   a.debug = g_debug;
   a.partial = nullptr;
+#if TDX_STAMPS
+  a.stamps = g_stamps;
+#endif
   a.ksplit = 1;
   a.steps_per_split = 0;
   a.tile_rows = kDmaRows;
@@ -1757,6 +1966,13 @@ static int run_dma(ConvArgs& a, const Choice& ch, hipStream_t st) {
   }
   return go(a, ch.tc, ch.tr);
 }
+
+#if TDX_STAMPS
+extern "C" int tdx_conv_gemm_stamps(void* ptr) {
+  g_stamps = (uint32_t*)ptr;
+  return TDX_OK;
+}
+#endif
 
 extern "C" int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* d) {
   ConvArgs a;

@@ -16,7 +16,11 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--L", type=int, default=200)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--force", type=int, nargs="*", default=[0], help="tdx_conv_gemm_force_small settings, one ms column each (first = baseline of the table)")
+ap.add_argument("--fuse-gn", action="store_true", help="GroupNorm of a conv's consumer in the conv's epilogue where the shape allows (engine.FUSE_GN_DEFAULT)")
 a = ap.parse_args()
+if a.fuse_gn:
+    from trajectorydiffusion_amd import engine
+    engine.FUSE_GN_DEFAULT = True
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 torch.manual_seed(0)
 m = TrajUNet([128, 128, 256, 512, 1024], diffusion_steps=500).cuda().eval().set_compute_dtype(dt)

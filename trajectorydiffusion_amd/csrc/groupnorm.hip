@@ -2,36 +2,61 @@
 //
 // A window is W = LPR * (16 B / sizeof(T)) consecutive channels (>= one whole group); the wave
 // sweeps the trajectory's L rows, 64/LPR rows per iteration, 16 bytes per lane, and reduces
-// with wavefront xor-shuffles (no LDS, no atomics).  Statistics are exact two-pass
+// with wavefront xor-shuffles (no atomics).  Statistics are exact two-pass
 // (mean, then centred sum of squares) in fp32.
+// Long trajectories (L > 64) are split over S = 2 or 4 waves of one workgroup, each holding its share of the rows in
+// registers: the waves exchange their partial sums through LDS (two barriers) and add them in a fixed order.  Shorter
+// per-wave sweeps need fewer registers (more waves per SIMD) and finer work items (no partly filled last round).
 #include "tdx_common.h"
 
 namespace {
 
 // NIT = row iterations per lane kept in registers (0: re-read the rows from L2 in each of the three sweeps).
-template <typename T, int NIT>
+template <typename T, int NIT, int S>
 __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int out_ld,
                                                            int out_off, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int B, int L, int C, int cpg,
-                                                           int lpr, float eps, int act) {
+                                                           int lpr, float eps, int act, int rows_per_part) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = VEC / 2;
   constexpr int NR = NIT > 0 ? NIT : 1;
-  const int lane = threadIdx.x & 63;
+  static_assert(S == 1 || NIT > 0, "split sweeps keep their rows in registers");
+  __shared__ float red[S > 1 ? 2 : 1][4][64][2];  // [pass][wave][column][lo, hi]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int W = lpr * VEC;
   const int wins = C / W;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long)B * wins) return;  // wave-uniform
-  const int b = (int)(wid / wins), win = (int)(wid % wins);
+  const long wid = ((long)blockIdx.x * 4 + wave) / S;  // (trajectory, window) item; S consecutive waves share one
+  const int part = wave % S;
+  const bool active = wid < (long)B * wins;            // wave-uniform, the same for the S waves of an item
+  if (S == 1 && !active) return;                       // (split sweeps: idle waves still take part in the barriers)
+  const int b = active ? (int)(wid / wins) : 0, win = active ? (int)(wid % wins) : 0;
   const int col = lane % lpr, rl = lane / lpr, rpi = 64 / lpr;
   const int ch = win * W + col * VEC;
   const T* xb = x + ((size_t)b * L) * x_ld + ch;
   const bool split = cpg < VEC;  // two groups inside one 16-byte vector (cpg == VEC/2)
+  // this wave's rows: [l0, l1)
+  const int l0 = S > 1 ? part * rows_per_part : 0;
+  const int l1 = !active ? 0 : (S > 1 ? (l0 + rows_per_part < L ? l0 + rows_per_part : L) : L);
 
+  int pass = 0;
   auto group_sum = [&](float& lo, float& hi) {
     for (int o = 32; o >= lpr; o >>= 1) {
       lo += __shfl_xor(lo, o, 64);
       hi += __shfl_xor(hi, o, 64);
+    }
+    if constexpr (S > 1) {  // the other waves' rows: partial sums through LDS, added in the order of the parts
+      if (rl == 0) *reinterpret_cast<float2*>(&red[pass][wave][col][0]) = make_float2(lo, hi);
+      __syncthreads();
+      const int w0 = wave - part;
+      lo = 0.f;
+      hi = 0.f;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const float2 v = *reinterpret_cast<const float2*>(&red[pass][w0 + k][col][0]);
+        lo += v.x;
+        hi += v.y;
+      }
+      ++pass;
     }
     if (!split) {
       lo += hi;
@@ -44,22 +69,22 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
   if constexpr (NIT > 0) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int l = rl + i * rpi;
-      held[i] = l < L ? *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld) : (u32x4){0u, 0u, 0u, 0u};
+      const int l = l0 + rl + i * rpi;
+      held[i] = l < l1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld) : (u32x4){0u, 0u, 0u, 0u};
     }
   }
   auto row = [&](int i, int l) -> u32x4 {
     if constexpr (NIT > 0) return held[i];
     else return *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld);
   };
-  const int nit = NIT > 0 ? NIT : (L - rl + rpi - 1) / rpi;
+  const int nit = NIT > 0 ? NIT : (L - rl + rpi - 1) / rpi;  // (NIT == 0 only with S == 1: l0 = 0, l1 = L)
 
   const float inv_cnt = 1.0f / ((float)cpg * (float)L);
   float s_lo = 0.f, s_hi = 0.f;
 #pragma unroll
   for (int i = 0; i < nit; ++i) {
-    const int l = rl + i * rpi;
-    if (l >= L) break;
+    const int l = l0 + rl + i * rpi;
+    if (l >= l1) break;
     float v[VEC];
     Elem<T>::unpack(row(i, l), v);
 #pragma unroll
@@ -74,8 +99,8 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
   float q_lo = 0.f, q_hi = 0.f;
 #pragma unroll
   for (int i = 0; i < nit; ++i) {
-    const int l = rl + i * rpi;
-    if (l >= L) break;
+    const int l = l0 + rl + i * rpi;
+    if (l >= l1) break;
     float v[VEC];
     Elem<T>::unpack(row(i, l), v);
 #pragma unroll
@@ -99,8 +124,8 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
   T* ob = out + ((size_t)b * L) * out_ld + out_off + ch;
 #pragma unroll
   for (int i = 0; i < nit; ++i) {
-    const int l = rl + i * rpi;
-    if (l >= L) break;
+    const int l = l0 + rl + i * rpi;
+    if (l >= l1) break;
     float v[VEC];
     Elem<T>::unpack(row(i, l), v);
 #pragma unroll
@@ -110,17 +135,23 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
 }
 
 template <typename T>
-void launch_gn(int nit, dim3 grid, hipStream_t st, const void* x, int x_ld, void* out, int out_ld, int out_off, const float* gamma,
-               const float* beta, int B, int L, int C, int cpg, int lpr, float eps, int act) {
-#define TDX_GN(N)                                                                                                              \
-  hipLaunchKernelGGL((groupnorm_act_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, x_ld, (T*)out, out_ld, out_off, gamma, \
-                     beta, B, L, C, cpg, lpr, eps, act)
-  if (nit <= 2) TDX_GN(2);
-  else if (nit <= 4) TDX_GN(4);
-  else if (nit <= 8) TDX_GN(8);
-  else if (nit <= 16) TDX_GN(16);
-  else if (nit <= 26) TDX_GN(26);
-  else TDX_GN(0);
+void launch_gn(int nit, int parts, int rows_per_part, dim3 grid, hipStream_t st, const void* x, int x_ld, void* out, int out_ld, int out_off,
+               const float* gamma, const float* beta, int B, int L, int C, int cpg, int lpr, float eps, int act) {
+#define TDX_GN(N, S)                                                                                                              \
+  hipLaunchKernelGGL((groupnorm_act_kernel<T, N, S>), grid, dim3(256), 0, st, (const T*)x, x_ld, (T*)out, out_ld, out_off, gamma, \
+                     beta, B, L, C, cpg, lpr, eps, act, rows_per_part)
+  if (parts == 4) {
+    if (nit <= 8) TDX_GN(8, 4);
+    else TDX_GN(16, 4);
+  } else if (parts == 2) {
+    if (nit <= 8) TDX_GN(8, 2);
+    else TDX_GN(16, 2);
+  } else if (nit <= 2) TDX_GN(2, 1);
+  else if (nit <= 4) TDX_GN(4, 1);
+  else if (nit <= 8) TDX_GN(8, 1);
+  else if (nit <= 16) TDX_GN(16, 1);
+  else if (nit <= 26) TDX_GN(26, 1);
+  else TDX_GN(0, 1);
 #undef TDX_GN
 }
 
@@ -182,14 +213,21 @@ extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t
     TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act: C=%d not a multiple of the %d-channel window", C, lpr * vec);
   TDX_CHECK_ARG(x_ld % vec == 0 && out_ld % vec == 0 && out_off % vec == 0 && x_ld >= C && out_off + C <= out_ld,
                 "tdx_groupnorm_act: x_ld/out_ld/out_off must be multiples of %d and fit", vec);
-  const long waves = (long)B * (C / (lpr * vec));
+  // Long trajectories: 2 or 4 waves per (trajectory, window), at most 16 row iterations each (a function of L and the
+  // window alone, so a trajectory is normalised the same way in every batch it is part of).
+  const int rpi = 64 / lpr;
+  int parts = L > 128 ? 4 : (L > 64 ? 2 : 1);
+  int rows_per_part = ((L + parts - 1) / parts + rpi - 1) / rpi * rpi;
+  if (parts > 1 && rows_per_part / rpi > 16) parts = 1;   // (very long trajectories: the one-wave sweep that re-reads its rows)
+  if (parts == 1) rows_per_part = L;
+  const long waves = (long)B * (C / (lpr * vec)) * parts;
   dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
-  const int nit = (L + 64 / lpr - 1) / (64 / lpr);
+  const int nit = (rows_per_part + rpi - 1) / rpi;
   if (dtype == TDX_F32)
-    launch_gn<float>(nit, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
+    launch_gn<float>(nit, parts, rows_per_part, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   else
-    launch_gn<__bf16>(nit, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
+    launch_gn<__bf16>(nit, parts, rows_per_part, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   TDX_CHECK_LAUNCH("groupnorm_act_kernel");
   return TDX_OK;
 }

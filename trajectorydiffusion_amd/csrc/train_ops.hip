@@ -641,9 +641,21 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     const float* k = base + (size_t)j * 3 * C + C;
     const float* v = base + (size_t)j * 3 * C + 2 * C;
     const float* go = dob + (size_t)i * C;
-    for (int c = 0; c < C; ++c) {
-      s = fmaf(q[c], k[c], s);
-      dp = fmaf(go[c], v[c], dp);
+    if ((C & 3) == 0 && ((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0)) {  // 16-byte loads, same summation order
+      for (int c = 0; c < C; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(q + c), bk = *reinterpret_cast<const f32x4*>(k + c);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(go + c), v4 = *reinterpret_cast<const f32x4*>(v + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = fmaf(a[e], bk[e], s);
+          dp = fmaf(g4[e], v4[e], dp);
+        }
+      }
+    } else {
+      for (int c = 0; c < C; ++c) {
+        s = fmaf(q[c], k[c], s);
+        dp = fmaf(go[c], v[c], dp);
+      }
     }
     s *= scale;
   }

@@ -9,7 +9,7 @@ B = 4096
 dt = torch.bfloat16
 lib = _lib.lib()
 print(f"{'shape':18s} {'ms':>8s} {'TB/s':>7s}")
-for L, C in [(200, 128), (100, 256), (50, 512), (25, 1024), (13, 1024), (13, 2048), (100, 128), (25, 512)]:
+for L, C in [(200, 128), (100, 256), (50, 512), (25, 1024), (13, 1024), (13, 2048), (100, 128), (25, 512), (24, 128), (12, 256), (6, 512), (3, 1024), (6, 1024), (12, 512), (24, 256)]:
     x = torch.randn((B, L, C), device="cuda").to(dt)
     y = torch.empty_like(x)
     g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")

@@ -39,8 +39,10 @@ for name, L, ci, co, k in (("128->256@100", 100, 128, 256, 3), ("256->256@100", 
     d = d[d[:, 15] > 1]          # workgroups of the main launch (the tail launch runs one tile per workgroup)
     tiles = d[:, 15].mean()
     nsteps = k * ci // 64
-    per = {n: float(d[:, i].mean() / tiles) for i, n in enumerate(NAMES)}
+    per = {n: float(d[:, i].mean() / tiles) for i, n in enumerate(NAMES)}   # (slots 12, 13: whole-kernel cycle / 100 MHz counters)
     rest = max(nsteps - (2 if per["s2 compute"] > 0 else 1), 1)
     print(f"{name}: {len(d)} workgroups, {tiles:.1f} tiles each, {nsteps} K-steps; cycles per tile (wave 0):")
     print("   " + "  ".join(f"{n}={v:.0f}" for n, v in per.items()))
+    clk = (d[:, 12] / d[:, 13].clamp(min=1)).median().item() * 100.0
+    print(f"   in-kernel clock (s_memtime / s_memrealtime x 100 MHz, median over workgroups): {clk:.0f} MHz")
     print(f"   per middle step: vmcnt {per['sN vmcnt'] / rest:.0f}  barrier {per['sN barrier'] / rest:.0f}  compute {per['sN compute'] / rest:.0f};  total per tile {sum(per.values()):.0f}")

@@ -1562,6 +1562,8 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   auto st_add = [&](int k, uint32_t d) {
     if (tid == 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(st_base + k * 4) += d;
   };
+  // in-kernel clock: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over the whole kernel
+  const uint32_t clk_t0 = st_now(), clk_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
   int g = 0, blk = 0;
   bool counted = false;  // the previous tile's epilogue stores are this wave's youngest vector-memory operations
@@ -1708,6 +1710,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     cp_co0 = nx_co0;
   }
 #if TDX_STAMPS
+  st_add(12, st_now() - clk_t0);
+  st_add(13, (uint32_t)__builtin_amdgcn_s_memrealtime() - clk_r0);
+  __syncthreads();
   if (p.stamps && tid < 16) p.stamps[blockIdx.x * 16 + tid] = *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(st_base + tid * 4);
 #endif
 #endif

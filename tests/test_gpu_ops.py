@@ -366,7 +366,9 @@ def test_conv_rejects_bad_arguments():
                                        # sweeps split over 2 / 4 waves of a workgroup (L > 64 / 128): odd lengths, a last part that is
                                        # short or a single row, idle waves in the last workgroup, and lengths past the split's reach
                                        (1, 65, 128, 2), (3, 129, 128, 0), (1, 199, 128, 2), (5, 97, 256, 2), (1, 128, 256, 0), (2, 513, 128, 2),
-                                       (1, 600, 128, 0)])
+                                       (1, 600, 128, 0),
+                                       # fewer than 8 rows: the window is widened (fewer rows per sweep) as far as C allows
+                                       (5, 3, 1024, 2), (4, 6, 512, 2), (3, 5, 256, 0), (2, 1, 2048, 2), (3, 2, 128, 0)])
 def test_groupnorm_act(dt, B, L, C, act):
     engine, _lib = _eng()
     g = torch.Generator().manual_seed(C + L)

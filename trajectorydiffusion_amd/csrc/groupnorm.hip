@@ -211,6 +211,17 @@ extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t
   while (lpr * vec < cpg) lpr <<= 1;
   if (lpr > 64 || C % (lpr * vec) != 0)
     TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act: C=%d not a multiple of the %d-channel window", C, lpr * vec);
+  // Very short trajectories (latent path: 3 and 6 rows): eight rows per sweep would leave most lanes idle and a wave would move
+  // a few hundred bytes.  Widen the window instead (fewer rows per sweep, longer contiguous row segments): the widest window
+  // with the best lane use.  A function of L and C alone.
+  if (L < 8) {
+    int best = lpr, best_used = 0, best_slots = 1;
+    for (int c = lpr; c <= 64 && C % (c * vec) == 0; c <<= 1) {
+      const int r = 64 / c, slots = (L + r - 1) / r * r;
+      if ((long)L * best_slots >= (long)best_used * slots) best = c, best_used = L, best_slots = slots;   // (L / slots >= best: ties go to the wider window)
+    }
+    lpr = best;
+  }
   TDX_CHECK_ARG(x_ld % vec == 0 && out_ld % vec == 0 && out_off % vec == 0 && x_ld >= C && out_off + C <= out_ld,
                 "tdx_groupnorm_act: x_ld/out_ld/out_off must be multiples of %d and fit", vec);
   // Long trajectories: 2 or 4 waves per (trajectory, window), at most 16 row iterations each (a function of L and the

@@ -9,6 +9,9 @@
 // per-wave sweeps need fewer registers (more waves per SIMD) and finer work items (no partly filled last round).
 #include "tdx_common.h"
 
+#ifndef TDX_GN_WIDE_L
+#define TDX_GN_WIDE_L 64
+#endif
 namespace {
 
 // NIT = row iterations per lane kept in registers (0: re-read the rows from L2 in each of the three sweeps).
@@ -211,14 +214,15 @@ extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t
   while (lpr * vec < cpg) lpr <<= 1;
   if (lpr > 64 || C % (lpr * vec) != 0)
     TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_groupnorm_act: C=%d not a multiple of the %d-channel window", C, lpr * vec);
-  // Very short trajectories (latent path: 3 and 6 rows): eight rows per sweep would leave most lanes idle and a wave would move
-  // a few hundred bytes.  Widen the window instead (fewer rows per sweep, longer contiguous row segments): the widest window
-  // with the best lane use.  A function of L and C alone.
-  if (L < 8) {
+  // Short trajectories: eight rows per sweep leave lanes idle (3 of 8 row slots at L = 3, 13 of 16 at L = 13) and a wave moves
+  // little.  Widen the window instead (fewer rows per sweep, longer contiguous row segments): the narrowest window with the
+  // best lane use at no more than 8 row iterations.  A function of L and C alone.
+  if (L < TDX_GN_WIDE_L) {
     int best = lpr, best_used = 0, best_slots = 1;
     for (int c = lpr; c <= 64 && C % (c * vec) == 0; c <<= 1) {
       const int r = 64 / c, slots = (L + r - 1) / r * r;
-      if ((long)L * best_slots >= (long)best_used * slots) best = c, best_used = L, best_slots = slots;   // (L / slots >= best: ties go to the wider window)
+      if (slots / r > 8) break;                                                                           // (at most 8 row iterations)
+      if ((long)L * best_slots > (long)best_used * slots) best = c, best_used = L, best_slots = slots;    // (L / slots > best: ties stay with the narrower window)
     }
     lpr = best;
   }

@@ -94,6 +94,8 @@ def parse_args(argv=None):
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--force-collectives", action="store_true", help="run the RCCL process group, the all_gather of x_0 and the barriers even at world size 1 "
+                    "(rehearses the N > 1 code path on a one-GPU box; needs RANK / MASTER_* from torch.distributed.run)")
     ap.add_argument("--low-latency", action="store_true", help="small-batch serving mode: split-K convs (TrajUNet.set_low_latency)")
     a = ap.parse_args(argv)
     if a.L is None:
@@ -120,7 +122,8 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
         t_last = torch.full((B,), a.T - 1, dtype=torch.long, device=dev)
     else:
         model = TrajUNet(SCHEDULE, diffusion_steps=a.T, res_blocks=2).to(dev).eval().set_compute_dtype(dtype).set_low_latency(a.low_latency)
-    gathered = torch.empty((world * B, 2, L // 8 if a.workload == "c5" else L), device=dev) if world > 1 else None
+    multi = dist is not None
+    gathered = torch.empty((world * B, 2, L // 8 if a.workload == "c5" else L), device=dev) if multi else None
 
     def one_step():
         if a.workload == "c5":   # eval_sd.ipynb cells 9-10 (x_T here plays the data trajectories)
@@ -132,13 +135,13 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
             x0 = dm.ddimBackward(x_T, cat, num, model, n_steps=a.ddim_steps, use_graph=not a.no_graph)
         else:
             x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered, x0.contiguous())
         return x0
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -152,7 +155,8 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
     fence()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(x0).all()
-    if world > 1:
+    if multi:
+        assert torch.equal(gathered[rank * B:(rank + 1) * B], x0)   # this rank's rows of the gathered x_0
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -220,7 +224,7 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_collectives:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         world = dist.get_world_size()
@@ -273,7 +277,7 @@ def main(argv=None):
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the other ranks must not idle at the final barrier for it
             out["cpu_baseline"] = cpu_baseline(L, a.T, workload=a.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

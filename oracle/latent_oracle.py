@@ -45,7 +45,7 @@ def condition_mix(sd: SD, time: torch.Tensor, cat_attr: torch.Tensor, num_attr: 
     time_embed = F.linear(h, sd[p + "time_embed_layers.2.weight"], sd[p + "time_embed_layers.2.bias"])
     cell = F.embedding(cat_attr[:, :-1], sd[p + "cell_index_embedder.weight"]).flatten(1)
     day = F.embedding(cat_attr[:, -1], sd[p + "day_embedder.weight"])
-    cat_embed = F.linear(torch.cat([cell, day], dim=1), sd[p + "categorical_fc.weight"], sd[p + "categorical_fc.bias"])
+    cat_embed = torch.cat([cell, day], dim=1)   # :136 as is: `categorical_fc` (:109) is constructed but never called by forward
     num_embed = F.linear(num_attr.to(w0.dtype), sd[p + "numerical_fc.weight"], sd[p + "numerical_fc.bias"])
     o = torch.cat([time_embed, cat_embed, num_embed], dim=1)
     o = F.linear(F.leaky_relu(o, 0.1), sd[p + "mix_fc.1.weight"], sd[p + "mix_fc.1.bias"])

@@ -44,7 +44,11 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="N > 1: reduce gradient slices under the backward program instead of after it")
     ap.add_argument("--check-overlap", action="store_true", help="N > 1: assert that both reduction schedules give identical gradients")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("--force-collectives", action="store_true", help="run the process group and every collective even at world size 1 "
+                    "(rehearses the RCCL code path on a one-GPU box; needs RANK / MASTER_* from torch.distributed.run)")
     a = ap.parse_args()
+    if a.force_collectives:
+        os.environ["TDX_FORCE_COLLECTIVES"] = "1"
     from trajectorydiffusion_amd.distributed import spawn_ranks_if_needed
     rc = spawn_ranks_if_needed(os.path.abspath(__file__), sys.argv[1:], a.gpus)   # before any GPU call
     if rc is not None:
@@ -53,8 +57,9 @@ def main():
     local = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    multi = world > 1 or a.force_collectives
     dist = None
-    if world > 1:
+    if multi:
         import faulthandler
         import torch.distributed as dist
         faulthandler.dump_traceback_later(90, exit=True)      # a stuck collective names its line instead of hanging the box
@@ -75,18 +80,18 @@ def main():
 
     def step():
         x_t = dm.diffusionForward(x0, t, eps)
-        if world > 1 and a.overlap:
+        if multi and a.overlap:
             loss = ts.forward_backward(x_t, t, cat, num, eps, sync_group=None)
         else:
             loss = ts.forward_backward(x_t, t, cat, num, eps)
-            if world > 1:
+            if multi:
                 ts.sync_gradients()
         ts.optimizer_step()
         return loss
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -99,7 +104,7 @@ def main():
     fence()
     el = (time.perf_counter() - t0) / a.steps
     assert torch.isfinite(loss).all()
-    if world > 1:
+    if multi:
         cdev = dev if a.backend == "nccl" else torch.device("cpu")
         tmax = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -111,7 +116,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "replicas diverged"
 
-    if world > 1 and a.check_overlap:
+    if multi and a.check_overlap:
         x_t = dm.diffusionForward(x0, t, eps)
         ts._passes = 1000                                   # replay the same dropout masks in both passes
         ts.forward_backward(x_t, t, cat, num, eps)
@@ -122,7 +127,10 @@ def main():
         ts.forward(x_t, t, cat, num)                        # dpred of the pass above is still in ts.dpred (same inputs, same masks)
         ts.backward(ts.dpred, sync_group=None, bucket_bytes=3 << 20)   # many small slices: exercises the readiness plan
         assert torch.equal(ts.flat_gradients(), after), "overlapped reduction differs from reduce-after-backward"
-        assert not torch.equal(local, after), "ranks hold different data, the mean must differ from the local gradient"
+        if world > 1:
+            assert not torch.equal(local, after), "ranks hold different data, the mean must differ from the local gradient"
+        else:
+            assert torch.equal(local, after), "world size 1: the mean over ranks is the local gradient"
         plan = ts._bucket_plan(3 << 20)
         print(f"rank {rank}: overlap check ok, {len(plan)} slices, first ready after launch {plan[0][2]} of {len(ts.bw.ops)}", file=sys.stderr, flush=True)
 
@@ -139,7 +147,7 @@ def main():
     out = {"metric": "training steps/sec, TrajUNet fp32 step (forward+backward+AdamW), L=%d" % L, "value": round(1 / el, 4), "unit": "steps/s",
            "trajectories_per_s": round(world * B / el, 2), "ms_per_step": round(1e3 * el, 2), "n_gpus": world, "scaling": "weak", "steps": a.steps, "warmup": a.warmup,
            "dtype": "fp32", "data": "synthetic", "config": {"workload": f"C4: TrajUNet training step, B={B} per GPU, L={L}, schedule {SCHEDULE}, dropout 0.1, AdamW",
-                      "parallelism": f"data parallel x{world}, gradient mean over {a.backend if world > 1 else 'nothing'}" + (", overlapped with backward" if a.overlap and world > 1 else "")},
+                      "parallelism": f"data parallel x{world}, gradient mean over {a.backend if multi else 'nothing'}" + (", overlapped with backward" if a.overlap and multi else "")},
            "forward_ms": round(ev[0].elapsed_time(ev[1]), 2), "backward_ms": round(ev[1].elapsed_time(ev[2]), 2),
            "optimizer_ms": round(ev[2].elapsed_time(ev[3]), 2),
            "model_tflops_per_gpu": round(3 * FLOP_PER_TRAJ_FWD * B / el / 1e12, 2), "peak_tflops_fp32_mfma": 157.3,
@@ -157,7 +165,7 @@ def main():
                     print(f"{tag:9s} {name:44s} {fn:24s} {ms:8.4f} ms", file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         faulthandler.cancel_dump_traceback_later()
         dist.barrier()
         dist.destroy_process_group()

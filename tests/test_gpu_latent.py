@@ -155,6 +155,31 @@ def test_condition_mix_block_matches_oracle():
         m(t.cuda(), bad.cuda(), num.cuda())
 
 
+def test_categorical_fc_is_a_state_dict_container_only(car):
+    """The reference's ConditionMixBlock.forward never calls `categorical_fc` (StableDiffusionBlocks.py:109 vs :134-140): changing
+    its weights must leave the block's and the whole SDUNet_CAR's output bit-identical (and changing a layer that IS used must not)."""
+    from trajectorydiffusion_amd import ConditionMixBlock
+    m = randomise(ConditionMixBlock(50, hidden_dim=128, embed_dim=128), 7).eval().cuda()
+    _, t, cat, num = inputs(6, 4, 8, 50, 8)
+    a = m(t.cuda(), cat.cuda(), num.cuda())
+    with torch.no_grad():
+        m.categorical_fc.weight.add_(1.0)
+        m.categorical_fc.bias.sub_(2.0)
+    assert torch.equal(m(t.cuda(), cat.cuda(), num.cuda()), a)
+    with torch.no_grad():
+        m.day_embedder.weight.add_(0.25)
+    assert not torch.equal(m(t.cuda(), cat.cuda(), num.cuda()), a)
+    car.cuda().set_compute_dtype(torch.float32)
+    x, t, cat, num = inputs(3, 4, 24, 500, 9)
+    y = car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+    with torch.no_grad():
+        car.embed_block.categorical_fc.weight.mul_(-3.0)
+    y2 = car(x.cuda(), t.cuda(), cat.cuda(), num.cuda())
+    with torch.no_grad():
+        car.embed_block.categorical_fc.weight.div_(-3.0)
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("cin,cout", [(128, 128), (128, 256), (512, 256)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cross_attention_res_matches_oracle(cin, cout, dtype):
@@ -297,8 +322,9 @@ def test_latent_sampling_seeded_philox_is_reproducible_and_shardable(car):
     assert torch.equal(a, b)
     lo = dm.diffusionBackward(x[:4].cuda(), cat[:4].cuda(), num[:4].cuda(), car)
     hi = dm.diffusionBackward(x[4:].cuda(), cat[4:].cuda(), num[4:].cuda(), car, first_sample=4)
-    # shards draw the noise of their global sample indices; the GEMM tiling may differ with the batch size, so compare to bf16 accuracy
-    assert rel(torch.cat([lo, hi]), a) < BF16_TOL
+    # shards draw the noise of their global sample indices, and every kernel keeps one summation order per output element whatever the
+    # batch size: batch shards reproduce the unsharded run bit for bit
+    assert torch.equal(torch.cat([lo, hi]), a)
     assert torch.isfinite(a).all()
     car.set_compute_dtype(torch.float32)
 
@@ -315,12 +341,54 @@ def test_c5_full_size_b4096_properties(car, car_sd):
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(62)).cuda()
     assert torch.equal(car(xd[perm], td[perm], cd[perm], nd[perm]), full[perm])
     half = car(xd[:2048], td[:2048], cd[:2048], nd[:2048])
-    assert rel(half, full[:2048]) < 1e-6 or torch.equal(half, full[:2048])
+    assert torch.equal(half, full[:2048])
     idx = [0, 1, 2047, 4095]
     ref = O.sdunet_car_forward(car_sd, x[idx], t[idx], cat[idx], num[idx], FULL, 500, 4)
     assert rel(full[idx], ref) < BF16_TOL
     car.set_compute_dtype(torch.float32)
     car._programs.clear()
+
+
+def test_c5_full_size_b4096_encode_sample_decode(car, car_sd, vae):
+    """eval_sd.ipynb cells 9-10 at B = 4096 (BASELINE.json C5): VAE_InvTrans.encode -> q-sample -> 2-step diffusionBackward (seeded Philox
+    noise) -> decode.  Finite, bitwise repeatable, rows of a shard equal the full run, and 4 rows against the oracle chain fed with the
+    noise the product drew (taken from a teacher run with injected noise: same kernels, same order)."""
+    from oracle import DiffusionOracle
+    from trajectorydiffusion_amd import DiffusionManager
+    B, T = 4096, 2
+    g = torch.Generator().manual_seed(65)
+    traj = torch.randn((B, 2, 199), generator=g)
+    _, _, cat, num = inputs(B, 4, 24, 500, 66)
+    eps = torch.randn((B, 4, 24), generator=g)
+    noise = torch.randn((T, B, 4, 24), generator=g)
+    car.cuda().set_compute_dtype(torch.bfloat16)
+    vae.cuda()
+    dm = DiffusionManager(0.0001, 0.05, T, device="cuda")
+    dm.seed = 99
+    tt = torch.full((B,), T - 1, dtype=torch.long)
+    cd, nd = cat.cuda(), num.cuda()
+
+    def chain(sl, **kw):
+        z0 = vae.encode(traj[sl].cuda())
+        zT = dm.diffusionForward(z0, tt[sl].cuda(), eps[sl].cuda())
+        return vae.decode(dm.diffusionBackward(zT, cd[sl], nd[sl], car, **kw))
+
+    full = chain(slice(0, B))
+    assert full.shape == (B, 2, 24) and torch.isfinite(full).all()
+    assert torch.equal(chain(slice(0, B)), full)                                   # repeatable bit for bit
+    assert torch.equal(chain(slice(1024, 2048), first_sample=1024), full[1024:2048])   # a shard draws its global rows' noise
+    # 4 rows against the oracle, with injected noise on both sides (bf16 denoiser: BF16_TOL on the latent scale)
+    inj = chain(slice(0, B), noise=noise.cuda())
+    idx = [0, 1, 2047, 4095]
+    vsd = cpu_sd(vae)
+    do = DiffusionOracle(0.0001, 0.05, T)
+    zT = do.q_sample(O.vae_encode(vsd, traj[idx]), tt[idx], eps[idx])
+    fn = lambda x, t: O.sdunet_car_forward(car_sd, x, t, cat[idx], num[idx], FULL, 500, 4)   # noqa: E731
+    ref = O.vae_decode(vsd, do.sample(zT, fn, lambda t: noise[t][idx]))
+    assert rel(inj[idx], ref) < BF16_TOL
+    car.set_compute_dtype(torch.float32)
+    car._programs.clear()
+    dm._samplers.clear()
 
 
 def test_latent_ddim_matches_oracle_loop(car, car_sd):

@@ -499,5 +499,19 @@ def test_didi_items_match_golden(golden_dir, tmp_path):
     deg = ds.denormalize(ll)
     raw = torch.stack([a for a, _ in ds.dataset_part])
     assert float((deg.cpu() - raw).abs().max()) < 2e-5  # degrees; fp32 ulp at 108.95 deg is 7.6e-6 (~0.8 m)
+    # getCellIndex (reference :127-135) on the normalised start / end points reproduces the golden categorical attributes bit for bit
+    for i in range(len(ds)):
+        src = ds.getCellIndex(ll[i, :, 0])
+        dst = ds.getCellIndex(ll[i, :, -1])
+        assert src.dtype == torch.long and src.shape == (2,)
+        np.testing.assert_array_equal(torch.cat([src, dst]).cpu().numpy(), g["cat"][i, :4])
+    # ... and the searchsorted(right=False) - 1 rule at its edges: a value ON a boundary belongs to the cell below it
+    b = torch.from_numpy(g["boundaries"])
+    probe = torch.tensor([float(b[1]), float(b[128]), -10.0, 10.0, 0.0049, float(b[255]) + 1e-3])
+    want = torch.searchsorted(b, probe) - 1
+    got = torch.stack([ds.getCellIndex(torch.stack([probe[j], probe[j + 1]]).cuda()) for j in (0, 2, 4)]).reshape(-1).cpu()
+    np.testing.assert_array_equal(got.numpy(), want.numpy())
+    with pytest.raises(Exception):
+        ds.getCellIndex(torch.zeros(2))   # CPU tensor: no fallback
     with pytest.raises(ValueError):
         DidiTrajectoryDataset(str(tmp_path), 200, [0, 0, 0], [1, 1, 1])

@@ -46,6 +46,26 @@ def test_oracle_runs_on_the_product_state_dict_small_model():
         O.sdunet_car_forward(m.state_dict(), x[:, :, :10], t, cat, num, [32, 64, 64], 50, 3)
 
 
+def test_condition_mix_never_calls_categorical_fc():
+    """StableDiffusionBlocks.py:134-140: forward concatenates the gathered cell / day embeddings as they are; `categorical_fc` (:109) is
+    a constructed-but-unused layer there (unlike TrajUNet's WideAndDeepEmbedBlock, TrajUNetBlocks.py:56).  The restatement must not
+    depend on its weights, and the categorical slice it feeds mix_fc is LeakyReLU of the raw embedding rows."""
+    from trajectorydiffusion_amd import ConditionMixBlock
+    torch.manual_seed(3)
+    m = ConditionMixBlock(50, hidden_dim=128, embed_dim=128)
+    sd = {"embed_block." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert sd["embed_block.categorical_fc.weight"].shape == (640, 640)    # still a state_dict entry (strict loading, Utils.py:10-12)
+    _, t, cat, num = small_inputs(5, 4, 8, 50, seed=4)
+    a = O.condition_mix(sd, t, cat, num, 50)
+    sd2 = dict(sd)
+    sd2["embed_block.categorical_fc.weight"] = torch.randn(640, 640)
+    sd2["embed_block.categorical_fc.bias"] = torch.randn(640)
+    assert torch.equal(O.condition_mix(sd2, t, cat, num, 50), a)
+    sd3 = dict(sd)
+    sd3["embed_block.day_embedder.weight"] = sd["embed_block.day_embedder.weight"] + 0.5
+    assert not torch.equal(O.condition_mix(sd3, t, cat, num, 50), a)
+
+
 def test_vae_oracle_shapes_and_the_decode_length_behaviour():
     from trajectorydiffusion_amd import VAE_InvTrans
     torch.manual_seed(1)

@@ -77,6 +77,18 @@ class DidiTrajectoryDataset(data.Dataset):
     def n_files(self) -> int:
         return len(self.file_paths)
 
+    def getCellIndex(self, point: torch.Tensor) -> torch.Tensor:
+        """City cell index of a normalised point (reference :127-135): point (2,) (lon, lat) -> (2,) long (lon_idx, lat_idx),
+        `searchsorted(city_cell_boundaries, v) - 1` per coordinate, by the search __getitem__'s kernel runs (tdx_cell_index)."""
+        _lib.require_device(point, "getCellIndex point")
+        v = point.reshape(-1)[:2].to(torch.float32).contiguous()
+        if v.numel() != 2:
+            raise TdxError(f"getCellIndex: point must hold (lon, lat), got shape {tuple(point.shape)}")
+        out = torch.empty(2, dtype=torch.long, device=v.device)
+        _lib.check(_lib.lib().tdx_cell_index(v.data_ptr(), self.city_cell_boundaries.to(v.device).data_ptr(), out.data_ptr(), 2,
+                                             _lib.stream_ptr()), "tdx_cell_index")
+        return out
+
     def normalizeBatch(self, lon_lat_raw: torch.Tensor, minutes: torch.Tensor):
         """lon_lat_raw (B, L, 2) fp32 degrees, minutes (B, L) fp32 -> (lon_lat (B,2,L), cat (B,5) i64, num (B,3), times (B,L))."""
         _lib.require_device(lon_lat_raw, "normalizeBatch lon_lat_raw")

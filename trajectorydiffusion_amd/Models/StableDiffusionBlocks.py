@@ -53,15 +53,16 @@ class ConditionMixBlock(_HipBlock):
              out: torch.Tensor) -> None:
         """Record forward() into `pg`: out (B, 7 * embed_dim) fp32.  All fp32 whatever the UNet's compute dtype.
         The LeakyReLU that opens mix_fc (:116) acts on the concatenation [time | categorical | numerical] (:140): each of the
-        three producers applies it to its own slice of the shared (B, 7H) buffer."""
+        three producers applies it to its own slice of the shared (B, 7H) buffer.  The categorical slice is the gathered cell / day
+        embeddings AS THEY ARE (:134-136): the reference constructs `categorical_fc` (:109) and never calls it, so it is kept here as
+        a state_dict container only and changing its weights changes nothing."""
         H, E, f32, F32 = self.hidden_dim, self.embed_dim, torch.float32, _lib.TDX_F32
         pe = pg.alloc((B, H), f32)
-        catvec = pg.alloc((B, 5 * H), f32)
         mix_in = pg.alloc((B, 7 * H), f32)
         pg.call("cond.gather", pg.lib.tdx_condmix_gather, time.data_ptr(), cat.data_ptr(), num.data_ptr(), self.pos_enc.data_ptr(), self.max_time,
                 fp32_param(self.cell_index_embedder.weight, "cell").data_ptr(), fp32_param(self.day_embedder.weight, "day").data_ptr(),
                 fp32_param(self.numerical_fc.weight, "num_w").data_ptr(), fp32_param(self.numerical_fc.bias, "num_b").data_ptr(),
-                pe.data_ptr(), catvec.data_ptr(), mix_in.data_ptr(), H, B, err.data_ptr(), keep=[time, cat, num, self.pos_enc, err, pe, catvec, mix_in])
+                pe.data_ptr(), None, mix_in.data_ptr(), H, B, err.data_ptr(), keep=[time, cat, num, self.pos_enc, err, pe, mix_in])
 
         def lin(src, k, mod, name, dst, dst_ld, off, act):
             pg.conv([Seg(src, k, k, 1, taps=1)], fp32_param(mod.weight, name + ".weight"), fp32_param(mod.bias, name + ".bias"), dst, dst_ld, B, 1,
@@ -70,11 +71,10 @@ class ConditionMixBlock(_HipBlock):
         h1 = pg.alloc((B, H), f32)
         lin(pe, H, self.time_embed_layers[0], "time0", h1, H, 0, ACT_LEAKY)
         lin(h1, H, self.time_embed_layers[2], "time2", mix_in, 7 * H, 0, ACT_LEAKY)
-        lin(catvec, 5 * H, self.categorical_fc, "cat_fc", mix_in, 7 * H, H, ACT_LEAKY)
         m1 = pg.alloc((B, 7 * H), f32)
         lin(mix_in, 7 * H, self.mix_fc[1], "mix1", m1, 7 * H, 0, ACT_LEAKY)
         lin(m1, 7 * H, self.mix_fc[3], "mix3", out, 7 * E, 0, ACT_SWISH)
-        for t in (pe, catvec, mix_in, h1, m1):
+        for t in (pe, mix_in, h1, m1):
             pg.release(t)
 
     def forward(self, time: torch.Tensor, cat_attr: torch.Tensor, num_attr: torch.Tensor) -> torch.Tensor:

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "tdx_q_sample": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "tdx_didi_items": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "tdx_didi_denorm": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "tdx_cell_index": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "tdx_metric_workspace_bytes": (_i64, [_i32]),
     "tdx_point_distribution": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "tdx_length_distribution": (_i32, [_vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -67,7 +67,19 @@ __global__ __launch_bounds__(256) void didi_denorm_kernel(const float* __restric
   out[2 * i + 1] = lon_lat[((size_t)b * 2 + 1) * L + l] * stats[5] + stats[2];
 }
 
+__global__ __launch_bounds__(64) void cell_index_kernel(const float* __restrict__ v, const float* __restrict__ bounds, int64_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) out[i] = cell_index(bounds, v[i]);
+}
+
 }  // namespace
+
+extern "C" int tdx_cell_index(const float* values, const float* bounds, int64_t* out, int32_t n, void* stream) {
+  TDX_CHECK_ARG(values && bounds && out && n > 0, "tdx_cell_index: bad arguments");
+  hipLaunchKernelGGL(cell_index_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, values, bounds, out, n);
+  TDX_CHECK_LAUNCH("cell_index_kernel");
+  return TDX_OK;
+}
 
 extern "C" int tdx_didi_items(const float* lon_lat_raw, const float* minutes, const float* stats, const float* bounds,
                               float* lon_lat, int64_t* cat, float* num, float* times, int32_t B, int32_t L, void* stream) {

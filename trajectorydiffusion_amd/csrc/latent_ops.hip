@@ -195,9 +195,11 @@ __global__ __launch_bounds__(256) void resample_rows_kernel(const T* __restrict_
 }
 
 // ---- ConditionMixBlock input gather (Models/StableDiffusionBlocks.py:131-140), fp32, hidden_dim = H ------------------------------
-//   pe (B, H) = pos_enc[time];  catvec (B, 5H) = [cell_emb[cat0..3] | day_emb[cat4]];
-//   mix_in (B, 7H) columns 6H..7H-1 = leaky0.1(numerical_fc(num)) (columns 0..6H-1 are written by the time / categorical GEMMs:
-//   the LeakyReLU that opens mix_fc acts on the whole concatenation, so each producer applies it to its own slice).
+//   pe (B, H) = pos_enc[time];  catvec (B, 5H) = [cell_emb[cat0..3] | day_emb[cat4]] (optional raw copy, may be null);
+//   mix_in (B, 7H) columns H..6H-1 = leaky0.1(catvec): the reference's forward concatenates the gathered embeddings as they are
+//   (:136,140); `categorical_fc` (:109) is constructed but never called there.  Columns 6H..7H-1 = leaky0.1(numerical_fc(num));
+//   columns 0..H-1 are written by the time GEMM.  The LeakyReLU that opens mix_fc (:116) acts on the whole concatenation, so each
+//   producer applies it to its own slice.
 __global__ __launch_bounds__(128) void condmix_gather_kernel(const int64_t* __restrict__ time, const int64_t* __restrict__ cat, const float* __restrict__ num,
                                                             const float* __restrict__ pos_enc, int max_time, const float* __restrict__ cell_emb,
                                                             const float* __restrict__ day_emb, const float* __restrict__ num_w, const float* __restrict__ num_b,
@@ -221,8 +223,11 @@ __global__ __launch_bounds__(128) void condmix_gather_kernel(const int64_t* __re
   const float n0 = num[(size_t)b * 3], n1 = num[(size_t)b * 3 + 1], n2 = num[(size_t)b * 3 + 2];
   for (int j = threadIdx.x; j < H; j += 128) {
     pe[(size_t)b * H + j] = pos_enc[(size_t)t * H + j];
-    for (int k = 0; k < 4; ++k) catvec[(size_t)b * 5 * H + k * H + j] = cell_emb[(size_t)ci[k] * H + j];
-    catvec[(size_t)b * 5 * H + 4 * H + j] = day_emb[(size_t)ci[4] * H + j];
+    for (int k = 0; k < 5; ++k) {
+      const float e = k < 4 ? cell_emb[(size_t)ci[k] * H + j] : day_emb[(size_t)ci[4] * H + j];
+      if (catvec) catvec[(size_t)b * 5 * H + k * H + j] = e;
+      mix_in[(size_t)b * 7 * H + (size_t)(k + 1) * H + j] = e > 0.f ? e : 0.1f * e;
+    }
     // F.linear: x @ W^T + b, W (H, 3); accumulate in the order ATen's addmm does for K = 3 (bias first)
     const float v = ((num_b[j] + n0 * num_w[j * 3]) + n1 * num_w[j * 3 + 1]) + n2 * num_w[j * 3 + 2];
     mix_in[(size_t)b * 7 * H + 6 * H + j] = v > 0.f ? v : 0.1f * v;
@@ -532,7 +537,7 @@ extern "C" int tdx_resample_rows(const void* x, void* out, int32_t B, int32_t li
 extern "C" int tdx_condmix_gather(const int64_t* time, const int64_t* cat, const float* num, const float* pos_enc, int32_t max_time,
                                   const float* cell_emb, const float* day_emb, const float* num_w, const float* num_b, float* pe, float* catvec,
                                   float* mix_in, int32_t hidden, int32_t B, int32_t* err_flag, void* stream) {
-  TDX_CHECK_ARG(time && cat && num && pos_enc && cell_emb && day_emb && num_w && num_b && pe && catvec && mix_in && err_flag,
+  TDX_CHECK_ARG(time && cat && num && pos_enc && cell_emb && day_emb && num_w && num_b && pe && mix_in && err_flag,
                 "tdx_condmix_gather: null pointer");
   TDX_CHECK_ARG(B > 0 && max_time > 0 && hidden > 0, "tdx_condmix_gather: bad sizes");
   hipLaunchKernelGGL(condmix_gather_kernel, dim3((unsigned)B), dim3(128), 0, (hipStream_t)stream, time, cat, num, pos_enc, max_time, cell_emb, day_emb,

@@ -46,6 +46,12 @@ def spawn_ranks_if_needed(script: str, argv: Sequence[str], gpus: int) -> Option
     return subprocess.run(rank_launch_command(script, argv, gpus), env=env).returncode
 
 
+def force_collectives() -> bool:
+    """TDX_FORCE_COLLECTIVES=1: run every collective of the multi-GPU paths even at world size 1 (where they are no-ops for the
+    data).  For rehearsing the RCCL code path (process group, side-stream all-reduces, all_gather) on a one-GPU box."""
+    return os.environ.get("TDX_FORCE_COLLECTIVES", "") == "1"
+
+
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     """[lo, hi) of `rank`'s contiguous slice; sizes differ by at most one, earlier ranks take the remainder."""
     if not 0 <= rank < world:
@@ -87,7 +93,7 @@ def allreduce_mean_(flat: torch.Tensor, group: Optional[dist.ProcessGroup] = Non
     if flat.dim() != 1 or not flat.is_contiguous():
         raise ValueError("allreduce_mean_: expected one contiguous 1-D buffer")
     world = dist.get_world_size(group)
-    if world == 1 or flat.numel() == 0:
+    if (world == 1 and not force_collectives()) or flat.numel() == 0:
         return flat
     step = max(1, bucket_bytes // flat.element_size())
     pending = [allreduce_slice_async(flat[lo:lo + step], group) for lo in range(0, flat.numel(), step)]

@@ -517,9 +517,9 @@ class TrainStep:
                 self._fold_padded()
                 return self.named_gradients()
             import torch.distributed as dist
-            from .distributed import allreduce_slice_async
+            from .distributed import allreduce_slice_async, force_collectives
             world = dist.get_world_size(sync_group)
-            plan = self._bucket_plan(bucket_bytes) if world > 1 else []
+            plan = self._bucket_plan(bucket_bytes) if world > 1 or force_collectives() else []
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=self.dev)
             main, comm, flat = torch.cuda.current_stream(), self._comm_stream, self._garena

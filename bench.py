@@ -65,14 +65,15 @@ def cpu_baseline(L, T_total, seconds_budget=20.0, workload="c2"):
             "sample": f"oracle (torch CPU fp32) B={B} L={L}: {steps} of {T_total} DDPM steps timed in {dt:.1f}s, scaled to {T_total} steps"}
 
 
-def newest_traffic_file(profiles_dir=None):
-    """profiles/r<NN>_pmc_traffic.json of the highest round present (PMC passes are separate rocprofv3 runs, so the figure
-    is stored per round by scripts/pmc_traffic.py; the bench line says which file it read)."""
+def newest_traffic_file(profiles_dir=None, dtype_name="bf16"):
+    """profiles/r<NN>_pmc_traffic[_fp32].json of the highest round present (PMC passes are separate rocprofv3 runs, so the figure
+    is stored per round by scripts/pmc_traffic.py; the bench line says which file it read and when it was measured)."""
     import glob
     import re
     best = None
-    for path in glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_traffic.json")):
-        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(path))
+    tag = "" if dtype_name == "bf16" else "_" + dtype_name
+    for path in glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_traffic*.json")):
+        m = re.match(r"r(\d+)_pmc_traffic%s\.json$" % tag, os.path.basename(path))
         if m and (best is None or int(m.group(1)) > best[0]):
             best = (int(m.group(1)), path)
     return best[1] if best else None
@@ -91,6 +92,7 @@ def parse_args(argv=None):
                     "VAE_InvTrans.encode -> q-sample to T-1 -> SDUNet_CAR sampling -> VAE_InvTrans.decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 (reference arithmetic) run of the same config")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 / C5 sub-objects of the default run")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"], help="ddim = config C3 (eta=0, --ddim-steps evenly spaced steps)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
@@ -103,8 +105,10 @@ def parse_args(argv=None):
     return a
 
 
-def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
-    """Time `steps` full sampling runs in one compute dtype; returns (elapsed seconds (max over ranks), model, x0)."""
+def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist, warm_t=None):
+    """Time `steps` full sampling runs in one compute dtype; returns (elapsed seconds (max over ranks), model).
+    warm_t: the warm-up runs stop after that many denoise steps (program build, weight packing and lazy kernel set-up are all paid;
+    only for sub-legs whose full run takes tens of seconds)."""
     from _synth import synth_inputs
     from trajectorydiffusion_amd import DiffusionManager, SDUNet_CAR, TrajUNet, VAE_InvTrans
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
@@ -125,16 +129,16 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
     multi = dist is not None
     gathered = torch.empty((world * B, 2, L // 8 if a.workload == "c5" else L), device=dev) if multi else None
 
-    def one_step():
+    def one_step(max_t=None):
         if a.workload == "c5":   # eval_sd.ipynb cells 9-10 (x_T here plays the data trajectories)
             z0 = vae.encode(x_T)
             zT = dm.diffusionForward(z0, t_last, eps0)
-            z = dm.diffusionBackward(zT, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
+            z = dm.diffusionBackward(zT, cat, num, model, max_t=max_t, first_sample=rank * B, use_graph=not a.no_graph)
             x0 = vae.decode(z)
         elif a.sampler == "ddim":
             x0 = dm.ddimBackward(x_T, cat, num, model, n_steps=a.ddim_steps, use_graph=not a.no_graph)
         else:
-            x0 = dm.diffusionBackward(x_T, cat, num, model, first_sample=rank * B, use_graph=not a.no_graph)
+            x0 = dm.diffusionBackward(x_T, cat, num, model, max_t=max_t, first_sample=rank * B, use_graph=not a.no_graph)
         if multi:
             dist.all_gather_into_tensor(gathered, x0.contiguous())
         return x0
@@ -147,7 +151,7 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist):
 
     x0 = None
     for _ in range(warmup):
-        x0 = one_step()
+        x0 = one_step(warm_t)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -173,17 +177,19 @@ def conv_roofline(model, a, dtype_name, dev):
     B = B // ns
     prog = model.program(B, L // 8 if a.workload == "c5" else L, dev, split_embed=True)
     prof = prog.pg.profile(repeats=3, inner=4)   # (4 launches per event pair: the event packets' own queue time stays out of the per-launch figure)
+    conv_roofline.last_hbm = hbm_roofline(prog.pg, prof, dtype_name, dev, B, ns, prog.x.shape[1], prog.x.shape[2])
     gemm = [(n, ms, fl) for n, fn, ms, fl in prof if fn == "tdx_conv_gemm"]
     gemm_ms, gemm_fl = sum(m for _, m, _ in gemm), sum(f for _, _, f in gemm)
     step_ms = sum(ms for _, _, ms, _ in prof)
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
     # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), stored per round
-    traffic, src = None, newest_traffic_file()
+    traffic, measured_on, src = None, None, newest_traffic_file(dtype_name=dtype_name)
     if src is not None:
         try:
             pm = json.load(open(src))
             if pm["workload"] == f"B={B}, L={L}, {dtype_name}":   # (B = trajectories per launch)
                 traffic = round(pm["conv_gemm_bytes_per_launch_avg"])
+                measured_on = pm.get("measured_on")
         except (OSError, KeyError, ValueError):
             pass
     es = 2 if dtype_name == "bf16" else 4
@@ -200,11 +206,119 @@ def conv_roofline(model, a, dtype_name, dev):
                 "trajectories_per_launch": B, "slices_per_step": ns}
     return {"bound": "mfma", "kernel": "conv_gemm_stream_kernel<...> via tdx_conv_gemm (a launch = one tdx_conv_gemm call on one batch slice of %d trajectories = main grid + optional small-tile tail grid; all %d calls of one slice's denoise step; the sampler runs %d slices per step)" % (B, len(gemm), ns),
             "achieved": round(achieved, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype_name], 4),
-            "traffic": traffic, "traffic_source": (os.path.relpath(src, ROOT) + " (rocprofv3 --pmc, bytes per launch, avg over the calls of one step)") if traffic is not None else None,
+            "traffic": traffic, "traffic_source": (os.path.relpath(src, ROOT) + " (rocprofv3 --pmc, bytes per launch, avg over the calls of one step; a stored figure of an earlier run of this workload, "
+                                                                   "PMC passes cannot run inside this process)") if traffic is not None else None,
+            "traffic_measured_on": measured_on if traffic is not None else None,
             "algorithmic_bytes_per_launch_avg": round((920976 + 831376) * es * B / len(gemm)), "launch_ms_avg": round(gemm_ms / len(gemm), 4), "launches": len(gemm),
             "flop_per_launch_avg": gemm_fl / len(gemm), "gemm_ms_per_step": round(gemm_ms * ns, 3),
             "other_kernels_ms_per_step": {k: round(v * ns, 4) for k, v in others.items()}, "all_kernels_ms_per_step": round(step_ms * ns, 3),
             "trajectories_per_launch": B, "slices_per_step": ns}
+
+
+HBM_PEAK = 8000.0   # GB/s, MI355X_MICROARCH.md (a float4 device copy measures 6 290 GB/s = 0.79 of it)
+
+
+def hbm_roofline(pg, prof, dtype_name, dev, B, ns, D, L):
+    """Roofline of the HBM-bound kernels of one denoise step (north_star: "achieved HBM GB/s for the norm/update kernels against MI355X
+    peak"): algorithmic bytes / HIP-event time.  GroupNorm(+Swish): every element read once and written once, summed over the step's
+    tdx_groupnorm_act launches (shapes taken from the recorded launch arguments).  Posterior update (tdx_ddpm_update, in-kernel Philox):
+    read x and eps, write x = 3 x 4 bytes per element; timed here on buffers of the sampler's slice size."""
+    import torch
+    from trajectorydiffusion_amd import _lib
+    es = 2 if dtype_name == "bf16" else 4
+    gn_ms = gn_bytes = 0.0
+    n_gn = 0
+    for (name, fn_name, ms, _), (_, _, args) in zip(prof, pg.ops):
+        if fn_name == "tdx_groupnorm_act":
+            gn_ms += ms
+            gn_bytes += 2.0 * args[7] * args[8] * args[9] * es   # (B, L, C) of this launch, read + write
+            n_gn += 1
+    x = torch.randn((B, D, L), device=dev)
+    eps = torch.randn((B, D, L), device=dev)
+    coef = torch.tensor([0.01, 0.99, 0.1], device=dev)
+    ctr = torch.tensor([3, 17, 5, 3], dtype=torch.int32, device=dev)
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    best = float("inf")
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            _lib.check(lib.tdx_ddpm_update(x.data_ptr(), eps.data_ptr(), None, coef.data_ptr(), x.numel(), 0, ctr.data_ptr(), 0, st), "tdx_ddpm_update")
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 8)
+    up_bytes = 3.0 * 4 * x.numel()
+    out = {"bound": "hbm", "peak": HBM_PEAK, "unit": "GB/s",
+           "ddpm_update": {"achieved": round(up_bytes / (best * 1e-3) / 1e9, 1), "frac": round(up_bytes / (best * 1e-3) / 1e9 / HBM_PEAK, 4),
+                           "ms_per_launch": round(best, 5), "algorithmic_bytes_per_launch": up_bytes, "trajectories_per_launch": B,
+                           "note": "in-kernel Philox noise: 3 x 4 B per element (4 800 B per trajectory at L=200)"}}
+    if n_gn:
+        out["groupnorm"] = {"achieved": round(gn_bytes / (gn_ms * 1e-3) / 1e9, 1), "frac": round(gn_bytes / (gn_ms * 1e-3) / 1e9 / HBM_PEAK, 4),
+                            "launches": n_gn, "ms_per_slice_step": round(gn_ms, 4), "ms_per_step": round(gn_ms * ns, 4),
+                            "algorithmic_bytes_per_slice_step": gn_bytes, "trajectories_per_launch": B,
+                            "note": "tdx_groupnorm_act launches of one slice's denoise step: every element read once + written once"}
+    return out
+
+
+def sub_leg(a, overrides, dtype_name, rank, world, dev, dist, steps=1, warmup=1, warm_t=None):
+    """One more BASELINE.json configuration inside the driver's run (N = 1 only): value + conv-GEMM roofline fraction."""
+    b = argparse.Namespace(**vars(a))
+    for k, v in overrides.items():
+        setattr(b, k, v)
+    if b.L is None or "workload" in overrides:
+        b.L = 199 if b.workload == "c5" else 200
+    el, model = run_leg(b, dtype_name, steps, warmup, rank, world, dev, dist, warm_t=warm_t)
+    n_denoise = b.ddim_steps if b.sampler == "ddim" else b.T
+    roof = conv_roofline(model, b, dtype_name, dev)
+    value = world * b.batch * steps / el
+    out = {"value": round(value, 3), "unit": "trajectories/s", "dtype": dtype_name, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 3),
+           "ms_per_denoise_step": round(1e3 * el / steps / n_denoise, 4),
+           "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": roof["peak"], "unit": "TFLOP/s", "frac": roof["frac"],
+                        "launch_ms_avg": roof["launch_ms_avg"], "launches": roof["launches"], "trajectories_per_launch": roof["trajectories_per_launch"]},
+           "hbm": getattr(conv_roofline, "last_hbm", None)}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_leg(dev, batch=1024, L=200, T=500, steps=5, warmup=2):
+    """BASELINE.json config 4: one TrajUNet training step (q-sample -> forward with dropout -> MSE -> backward -> fused AdamW), fp32 as the
+    reference trains (train.ipynb:198-209), B = 1024 on this GPU.  scripts/train_bench.py is the full tool (breakdown, data parallel)."""
+    from _synth import synth_inputs, synth_noise
+    from trajectorydiffusion_amd import DiffusionManager, TrajUNet
+    from trajectorydiffusion_amd.training import TrainStep
+    torch.manual_seed(0)
+    model = TrajUNet(SCHEDULE, diffusion_steps=T, res_blocks=2).to(dev)
+    dm = DiffusionManager(1e-4, 0.05, T, device=str(dev))
+    x0, t, cat, num = synth_inputs(batch, L, T, seed=7)
+    x0, t, cat, num = x0.to(dev), t.to(dev), cat.to(dev), num.to(dev)
+    eps = synth_noise(0, (batch, 2, L), seed=7).to(dev)
+    ts = TrainStep(model, batch, L, dev, lr=5e-4)
+
+    def step():
+        x_t = dm.diffusionForward(x0, t, eps)
+        loss = ts.forward_backward(x_t, t, cat, num, eps)
+        ts.optimizer_step()
+        return loss
+
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss).all()
+    tf = 3 * FLOP_PER_TRAJ_STEP * batch / el / 1e12
+    out = {"value": round(1.0 / el, 4), "unit": "training steps/s", "trajectories_per_s": round(batch / el, 1), "ms_per_step": round(1e3 * el, 2), "dtype": "fp32",
+           "steps": steps, "warmup": warmup, "config": f"C4: TrajUNet training step, B={batch}, L={L}, dropout 0.1, fused AdamW, one GPU (data parallel: scripts/train_bench.py --gpus N --overlap)",
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK["fp32"], "unit": "TFLOP/s", "frac": round(tf / PEAK["fp32"], 4),
+                        "note": "whole step, counting 3 x the forward's algorithmic FLOPs (forward + data gradient + weight gradient)"},
+           "loss": float(loss)}
+    del ts, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main(argv=None):
@@ -260,6 +374,8 @@ def main(argv=None):
             "model_tflops": round(value * n_denoise * FLOP_PER_TRAJ_STEP / 1e12 / world, 2),
             "roofline": conv_roofline(model, a, a.dtype, dev),
         }
+    if out is not None:
+        out["hbm"] = getattr(conv_roofline, "last_hbm", None)
     del model
     torch.cuda.empty_cache()
     # The reference's own arithmetic (fp32: exact f32 MFMA, the 1e-4 parity path) on the same config, in the same run:
@@ -271,8 +387,28 @@ def main(argv=None):
                            "ms_per_denoise_step": round(1e3 * el32 / n_denoise, 4),
                            "model_tflops": round(B / el32 * n_denoise * FLOP_PER_TRAJ_STEP / 1e12, 2),
                            "roofline": conv_roofline(m32, a, "fp32", dev)}
+            out["fp32"]["hbm"] = getattr(conv_roofline, "last_hbm", None)
         del m32
         torch.cuda.empty_cache()
+    # The other BASELINE.json configurations, in the same run (one GPU, default workload only): C3 = DDIM 50 steps at B = 65 536,
+    # C4 = the fp32 training step at B = 1024, C5 = the latent path at B = 4096 (bf16, and fp32 = the arithmetic that stays inside the
+    # north_star's tolerance for that model: tests/test_gpu_latent.py).  A leg that fails is reported as an error string, the line survives.
+    if rank == 0 and world == 1 and a.workload == "c2" and a.sampler == "ddpm" and a.dtype == "bf16" and not a.no_other_configs and a.batch == 4096 and a.T == 500:
+        def guarded(fn):
+            try:
+                return fn()
+            except Exception as e:   # noqa: BLE001
+                torch.cuda.empty_cache()
+                return {"error": f"{type(e).__name__}: {e}"[:400]}
+        out["c3"] = guarded(lambda: dict(sub_leg(a, {"sampler": "ddim", "batch": 65536}, "bf16", rank, world, dev, dist),
+                                         config=f"C3: TrajUNet DDIM {a.ddim_steps}-step sampling (eta = 0, T={a.T} table; not in the reference), B=65536 on one GPU, L=200"))
+        out["c4"] = guarded(lambda: train_leg(dev))
+        out["c5"] = guarded(lambda: dict(sub_leg(a, {"workload": "c5"}, "bf16", rank, world, dev, dist),
+                                         config="C5: latent path, VAE_InvTrans.encode -> SDUNet_CAR 500-step DDPM sampling -> decode, B=4096, L=199 (parity unpinned by the reference)",
+                                         note="bf16 SDUNet_CAR measures 2.5e-2 worst element / 2.2e-2 relative L2 against the fp32 restatement at B=4 (tests/test_gpu_latent.py): "
+                                              "outside the north_star's 1e-2 bf16 tolerance; the in-tolerance figure for this model is the fp32 one below"))
+        if "error" not in out["c5"]:
+            out["c5"]["fp32"] = guarded(lambda: sub_leg(a, {"workload": "c5"}, "fp32", rank, world, dev, dist, steps=1, warmup=1, warm_t=3))
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the other ranks must not idle at the final barrier for it
             out["cpu_baseline"] = cpu_baseline(L, a.T, workload=a.workload)

@@ -68,7 +68,13 @@ class TrainStep:
         self._repack_torch: List[Callable[[], None]] = []  # the weight layouts as torch statements (tests check tdx_pack_weights against them)
         self._packs: List[Tuple["_Src", torch.Tensor, int, str]] = []
         self._pack_tab: Optional[torch.Tensor] = None
-        self._agrad: Dict[int, torch.Tensor] = {}   # id(activation) -> gradient buffer (zeroed every step)
+        self._agrad: Dict[int, torch.Tensor] = {}   # id(activation) -> gradient buffer
+        # id(activation) -> channel slices [lo, hi) of its gradient buffer that the backward program has written so far, in emission
+        # (= execution) order.  The FIRST writer of a slice overwrites it (accumulate = 0 / no residual operand), later ones add: a
+        # buffer whose every channel is first written that way needs no zero fill per step, and its first data-gradient conv carries
+        # no residual operand (one tensor read less, and the persistent conv kernel takes the launch)
+        self._gwritten: Dict[int, List[Tuple[int, int]]] = {}
+        self._gzero: List[torch.Tensor] = []        # gradient buffers that still need the per-step zero fill
         self._keep: List[torch.Tensor] = []
         self.params = dict(model.named_parameters())
         for n, p in self.params.items():
@@ -106,6 +112,18 @@ class TrainStep:
         if g is None:
             g = self._agrad[id(t)] = self._new(*t.shape)
         return g
+
+    def first_write(self, t: torch.Tensor, lo: int = 0, width: Optional[int] = None) -> bool:
+        """Called while the backward program is emitted, by a launch that writes channels [lo, lo + width) of every row of G(t):
+        True when no earlier launch has written any of them (the launch must then overwrite), False when it must accumulate."""
+        hi = lo + (t.shape[-1] if width is None else width)
+        spans = self._gwritten.setdefault(id(t), [])
+        fresh = all(hi <= a or lo >= b for a, b in spans)
+        if fresh:
+            spans.append((lo, hi))
+        elif not any(a <= lo and hi <= b for a, b in spans):
+            raise TdxError("TrainStep: a gradient write overlaps an earlier one only partly")
+        return fresh
 
     def PG(self, p: torch.Tensor) -> torch.Tensor:
         """Gradient buffer of a parameter (or of a padded stand-in registered with _pad)."""
@@ -220,7 +238,8 @@ class TrainStep:
             gptr = go.data_ptr() + 4 * off
             if res is not None:
                 gr = self.G(res)
-                bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout, 1, F32)
+                bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout,
+                        0 if self.first_write(res, 0, cout) else 1, F32)
             for b in biases:
                 bw.call(name + ".dbias", lib.tdx_colsum, gptr, ld, N, cout, self.PG(b).data_ptr(), 1, F32, self.red_ws.data_ptr())
             if ebias is not None:
@@ -239,11 +258,15 @@ class TrainStep:
                 if s.stride == 2:
                     if off != 0 or ld != cout or s.ch_off != 0 or s.ld != s.cin:
                         raise TdxError(f"{name}: stride-2 data gradient needs plain tensors")
-                    engine.conv_dgrad_stride2(bw, go, wd[0], wd[1], gs, B, s.lin, cout, s.cin, accumulate=True)
+                    engine.conv_dgrad_stride2(bw, go, wd[0], wd[1], gs, B, s.lin, cout, s.cin, accumulate=not self.first_write(s.t, 0, s.cin))
                 elif s.lvirt != s.lin:
                     du = self._new(B, s.lvirt, s.cin)
                     bw.conv([engine.Seg(go, ld, cout, lout, taps=s.taps, ch_off=off)], wd, None, du, s.cin, B, s.lvirt, s.cin, name=name + ".dgrad")
-                    bw.call(name + ".fold", lib.tdx_upsample_fold, du.data_ptr(), s.cin, 0, gs.data_ptr(), s.ld, s.ch_off, B, s.lin, s.lvirt, s.cin, 1, F32)
+                    bw.call(name + ".fold", lib.tdx_upsample_fold, du.data_ptr(), s.cin, 0, gs.data_ptr(), s.ld, s.ch_off, B, s.lin, s.lvirt, s.cin,
+                            0 if self.first_write(s.t, s.ch_off, s.cin) else 1, F32)
+                elif self.first_write(s.t, s.ch_off, s.cin):
+                    bw.conv([engine.Seg(go, ld, cout, lout, taps=s.taps, ch_off=off)], wd, None, gs, s.ld, B, s.lin, s.cin, out_off=s.ch_off,
+                            name=name + ".dgrad")
                 else:
                     bw.conv([engine.Seg(go, ld, cout, lout, taps=s.taps, ch_off=off)], wd, None, gs, s.ld, B, s.lin, s.cin, out_off=s.ch_off,
                             res=gs[..., s.ch_off:], res_ld=s.ld, name=name + ".dgrad")
@@ -259,7 +282,7 @@ class TrainStep:
             go, gx = self.G(out), self.G(x)
             self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_bwd, x.data_ptr(), x.shape[-1], go.data_ptr(), out.shape[-1], out_off, gx.data_ptr(),
                          x.shape[-1], 0, gam.data.data_ptr() + 4 * p_off, bet.data.data_ptr() + 4 * p_off, ra.data_ptr(), rb.data_ptr(), B, L, Cn, groups,
-                         mod.eps, act, 1, F32)
+                         mod.eps, act, 0 if self.first_write(x, 0, Cn) else 1, F32)
             for rows, p in ((ra, gam), (rb, bet)):
                 self.bw.call(name + ".dparam", lib.tdx_colsum, rows.data_ptr(), Cn, B, Cn, self.PG(p).data_ptr() + 4 * p_off, 1, F32, self.red_ws.data_ptr())
         self._back.append(backward)
@@ -365,8 +388,8 @@ class TrainStep:
         self.conv(key + "qkv", [_Src(a, Cn, lm, ab.qkv_getter[1].weight, taps=1)], 3 * Cn, lm, qkv, biases=[ab.qkv_getter[1].bias])
         o = self._new(B, lm, Cn)
         self.fw.call(key + "attention", lib.tdx_attention, qkv.data_ptr(), o.data_ptr(), B, lm, Cn, F32)
-        self._back.append(lambda: self.bw.call(key + "attention.bwd", lib.tdx_attention_bwd, qkv.data_ptr(), self.G(o).data_ptr(), self.G(qkv).data_ptr(),
-                                               B, lm, Cn))
+        self._back.append(lambda: (self.first_write(qkv), self.bw.call(key + "attention.bwd", lib.tdx_attention_bwd, qkv.data_ptr(), self.G(o).data_ptr(),
+                                                                         self.G(qkv).data_ptr(), B, lm, Cn)))
         x2 = self._new(B, lm, Cn)
         self.conv(key + "proj", [_Src(o, Cn, lm, ab.project_out.weight, taps=1)], Cn, lm, x2, biases=[ab.project_out.bias], res=x1)
         cur = self._resblock(key + "res2.", ab.res2, [(x2, Cn)], lm)
@@ -389,8 +412,20 @@ class TrainStep:
         self.out4 = self._new(B, L, 4)
         self.conv("head.conv", [_Src(ah, cs[0], L, head4)], 4, L, self.out4, biases=[hb4])
         # ---- backward program = the tape in reverse ----
+        self.first_write(self.out4)                  # backward() itself writes the loss gradient there (all 4 padded channels)
         for f in reversed(self._back):
             f()
+        # gradient buffers that some launch only ever adds to (per-trajectory embed rows, the embedding MLP's small ends) keep their
+        # per-step zero fill; every other one is overwritten by its first writer
+        for key, g in self._agrad.items():
+            spans = sorted(self._gwritten.get(key, []))
+            end = 0
+            for a, b in spans:
+                if a > end:
+                    break
+                end = max(end, b)
+            if end < g.shape[-1]:
+                self._gzero.append(g)
         self.pred = self._new(B, 2, L)
         self.dpred = self._new(B, 2, L)
         self.loss = self._new(1)
@@ -503,7 +538,7 @@ class TrainStep:
         the order of the sum is fixed)."""
         sync = sync_group is not False
         with torch.no_grad():
-            for g in self._agrad.values():
+            for g in self._gzero:
                 g.zero_()
             self.flat_gradients().zero_()
             for n, g in self.grads.items():

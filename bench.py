@@ -164,7 +164,7 @@ def run_leg(a, dtype_name, steps, warmup, rank, world, dev, dist, warm_t=None):
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    dm._samplers.clear()   # the sampler owns GBs of workspace and a captured graph
+    dm.release_samplers()   # the sampler owns GBs of workspace and a captured graph
     return elapsed, model
 
 

@@ -125,8 +125,10 @@ typedef struct {
   int32_t stats_out_ld, stats_out_off;
 } tdx_conv_desc;
 int tdx_conv_gemm(const tdx_conv_desc* host_desc, void* stream);
-/* 1 if tdx_conv_gemm can run this descriptor WITH its fused GroupNorm, 0 if the caller must run
- * tdx_groupnorm_act separately (trajectories longer than a 256-row tile, odd channel counts, ...). */
+/* > 0 if tdx_conv_gemm can run this descriptor WITH its fused GroupNorm, 0 if the caller must run
+ * tdx_groupnorm_act separately (trajectories longer than a 256-row tile, odd channel counts, ...).
+ * 2 = the persistent kernel takes it (bf16, stride-1 un-resampled sources, groups of 8 .. 64 channels, cout <= 1024): the form that
+ * is faster than conv + stand-alone GroupNorm when tiles of whole trajectories fill their 256 rows; 1 = the one-tile kernel. */
 int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* host_desc);
 /* 1 if tdx_conv_gemm can run this descriptor WITH its norm[] / stats_out fields (today: bf16, one 128-channel k=3 segment,
  * 128 output channels, enough rows to fill the chip: the HBM-bound full-resolution layers, where a separate GroupNorm pass

@@ -388,7 +388,7 @@ def test_c5_full_size_b4096_encode_sample_decode(car, car_sd, vae):
     assert rel(inj[idx], ref) < BF16_TOL
     car.set_compute_dtype(torch.float32)
     car._programs.clear()
-    dm._samplers.clear()
+    dm.release_samplers()
 
 
 def test_latent_ddim_matches_oracle_loop(car, car_sd):

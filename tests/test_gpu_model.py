@@ -317,14 +317,14 @@ def test_c3_full_size_65536_one_gpu(model):
         full = dm.ddimBackward(xg, cg, ng, model, n_steps=2)
         assert torch.isfinite(full).all()
         assert torch.equal(dm.ddimBackward(xg, cg, ng, model, n_steps=2), full)
-        dm._samplers.clear()
+        dm.release_samplers()
         model._programs.clear()
         torch.cuda.empty_cache()
         h = B // 2
         parts = [dm.ddimBackward(xg[a:a + h], cg[a:a + h], ng[a:a + h], model, n_steps=2) for a in (0, h)]
         assert torch.equal(torch.cat(parts), full)
     finally:
-        dm._samplers.clear()
+        dm.release_samplers()
         model._programs.clear()
         torch.cuda.empty_cache()
         model.set_compute_dtype(torch.float32)

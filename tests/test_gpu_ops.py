@@ -328,6 +328,71 @@ def test_conv_with_fused_consumer_groupnorm(dt, B, L, Ci, Co, cpg, act, raw):
     assert rel(unrows(y3)[:, 16:], ref) < tol
 
 
+@pytest.mark.parametrize("B,L,Ci,Co,cpg,act,raw,mode", [
+    (700, 25, 128, 1024, 32, 2, False, 1),    # ResnetBlock conv1 at the 1024-channel level: embed rows, normalised output only; 280 tiles (> one per CU)
+    (640, 13, 256, 1024, 32, 0, True, 2),     # the attention's proj: residual, raw rows too, no activation
+    (300, 50, 128, 512, 16, 2, False, 0),
+    (260, 25, 128, 256, 8, 2, True, 1),
+    (200, 13, 128, 512, 64, 2, False, 0),     # groups of 64 channels (the decoder's concat GroupNorm over one half)
+    (100, 24, 128, 128, 8, 2, False, 2),      # 128-channel tiles
+    (2000, 3, 128, 1024, 32, 2, False, 2),    # latent path: 85 trajectories per tile
+    (5, 13, 128, 1024, 32, 2, False, 1),      # one partly filled tile
+])
+def test_conv_fused_groupnorm_persistent_form(B, L, Ci, Co, cpg, act, raw, mode):
+    """The consumer's GroupNorm(+Swish) in the epilogue of the PERSISTENT conv kernel (bf16; tdx_conv_gemm_gn_fusable() == 2): against the
+    torch statement, against conv + stand-alone tdx_groupnorm_act, bitwise repeatable, and invariant to how the batch is cut."""
+    engine, _lib = _eng()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(L * 11 + Co + mode)
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, 3, generator=g) / (3 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    eb = torch.randn(B, Co, generator=g) if mode == 1 else None
+    res = torch.randn(B, Co, L, generator=g) if mode == 2 else None
+    gamma, beta = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    pre = F.conv1d(q(x, dt), q(w, dt), b, padding=1)
+    if eb is not None:
+        pre = pre + eb[:, :, None]
+    if res is not None:
+        pre = pre + q(res, dt)
+    ref = F.group_norm(pre, Co // cpg, gamma, beta, eps=1e-6)
+    ref = swish(ref) if act == 2 else ref
+
+    class Holder:
+        weight, bias, eps = gamma.cuda(), beta.cuda(), 1e-6
+
+    def run(lo=0, hi=B, fuse=True):
+        n = hi - lo
+        pg = engine.Program(torch.device("cuda"), dt)
+        pg.fuse_gn = fuse
+        out = torch.full((n, L, Co), float("nan"), device="cuda", dtype=dt) if raw else None
+        y = torch.zeros((n, L, Co + 8), device="cuda", dtype=dt)
+        spec = engine.GnSpec(Holder, "t", 0, cpg, act, y, Co + 8, 8)
+        pg.conv([engine.Seg(rows(x[lo:hi], dt), Ci, Ci, L)], engine.pack_conv_weight(w.cuda(), dt), b.cuda(), out, Co, n, L, Co,
+                res=None if res is None else rows(res[lo:hi], dt), res_ld=Co, ebias=None if eb is None else eb[lo:hi].contiguous().cuda(), ebias_ld=Co, gn=spec)
+        pg.run()
+        torch.cuda.synchronize()
+        return pg, out, y
+    pg, out, y = run()
+    assert [n for n, _, _ in pg.ops] == ["conv"]
+    d = pg.keep[[type(k).__name__ for k in pg.keep].index("ConvDesc")]
+    assert _lib.lib().tdx_conv_gemm_gn_fusable(d) == 2, "expected the persistent kernel's GroupNorm epilogue"
+    got = unrows(y)
+    assert float(got[:, :8].abs().max()) == 0.0
+    assert rel(got[:, 8:], ref) < 1.5e-2
+    if raw:
+        assert rel(unrows(out), pre) < TOL[dt]
+    _, _, y2 = run()
+    assert torch.equal(y, y2)                       # fixed summation order: bitwise reproducible
+    cut = max(1, B // 3)
+    _, _, ya = run(0, cut)
+    _, _, yb = run(cut, B)
+    assert torch.equal(torch.cat([ya, yb]), y)      # a trajectory's statistics do not depend on its place in a tile or in the batch
+    _, _, y3 = run(fuse=False)                      # conv + tdx_groupnorm_act: statistics of the bf16-rounded rows instead of the fp32 ones
+    assert rel(unrows(y3)[:, 8:], ref) < 1.5e-2
+    assert rel(unrows(y3)[:, 8:], got[:, 8:]) < 1.5e-2
+
+
 def test_conv_fused_groupnorm_falls_back_when_trajectory_exceeds_tile():
     engine, _lib = _eng()
     B, L, C = 2, 300, 128

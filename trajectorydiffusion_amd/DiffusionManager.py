@@ -94,6 +94,15 @@ class DiffusionManager:
                                               0, ctr.data_ptr(), 0, _lib.stream_ptr()), "tdx_ddpm_update")
         return out
 
+    def release_samplers(self) -> None:
+        """Drop the cached graph-replayed sampler (workspaces + captured HIP graphs) NOW.  A sampler and this object reference each
+        other, so without this call a replaced sampler lives until Python's cyclic collector finds it, and its captured graphs are
+        then destroyed at an arbitrary point, possibly in the middle of another graph's capture or launch (round 3: a host-side crash
+        inside a later hipGraphLaunch that went away once destruction happened at defined points)."""
+        for smp in self._samplers.values():
+            smp.close()
+        self._samplers = {}
+
     @staticmethod
     def seed_words(seed: int, t: int = 0):
         """Device words {step, seed_lo, seed_hi, stream} of tdx_ddpm_update's step_ctr for a 62-bit seed."""
@@ -129,8 +138,9 @@ class DiffusionManager:
             key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, max_t, "ddpm", getattr(model, "low_latency", False))
             smp = self._samplers.get(key)
             if smp is None or not smp.valid():
+                self.release_samplers()       # keep one: a sampler owns GBs of workspace (and captured graphs: released HERE, not by the GC)
                 smp = GraphSampler(self, model, x_T.shape[0], x_T.shape[2], x_T.device, max_t)
-                self._samplers = {key: smp}  # keep one: a sampler owns GBs of workspace
+                self._samplers = {key: smp}
             return smp.sample(x_T, cat_attr, num_attr, noise=noise, first_sample=first_sample, use_graph=use_graph)
         # generic callable model: the reference loop with the fused update kernel
         B = x_T.shape[0]
@@ -156,6 +166,7 @@ class DiffusionManager:
         key = (id(model), x_T.shape[0], x_T.shape[2], model.compute_dtype, x_T.device, n_steps, "ddim", getattr(model, "low_latency", False))
         smp = self._samplers.get(key)
         if smp is None or not smp.valid():
+            self.release_samplers()
             smp = GraphSampler(self, model, x_T.shape[0], x_T.shape[2], x_T.device, self.T, ddim_steps=n_steps)
             self._samplers = {key: smp}
         return smp.sample(x_T, cat_attr, num_attr, use_graph=use_graph)

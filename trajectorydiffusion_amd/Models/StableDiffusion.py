@@ -26,6 +26,8 @@ class SDProgram:
     def __init__(self, model: "SDUNet_CAR", B: int, L: int, dtype: torch.dtype, device: torch.device):
         self.B, self.L, self.dtype = B, L, dtype
         pg = engine.Program(device, dtype)
+        if engine.FUSE_GN_ENV is None and engine.FUSE_GN_DEFAULT is False:
+            pg.fuse_gn = "auto"   # the out projections' GroupNorm in their epilogue: 1.9 % per denoise step (profiles/r3_c5_gn_fusion.txt)
         self.pg = pg
         f32 = torch.float32
         D = model.traj_dim

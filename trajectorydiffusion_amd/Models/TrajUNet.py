@@ -57,8 +57,8 @@ class UNetProgram:
     def _emit_unet(self, m: "TrajUNet", packed: Dict[str, torch.Tensor]) -> None:
         """Dataflow: every conv GEMM is recorded together with the GroupNorm(+Swish) of its consumer (engine.Program.conv,
         `gn=`).  By default that GroupNorm runs as its own tdx_groupnorm_act launch right behind the conv (measured faster
-        on MI355X, profiles/r1_gn_fusion_ablation.txt); with Program.fuse_gn it is applied in the conv's epilogue where the
-        library can.  Stand-alone GroupNorms with no conv producer: the one after the stem and the skip halves of the
+        on MI355X for every layer, also against the persistent kernel's fused epilogue: profiles/r3_gn_per_layer_ablation.txt);
+        with Program.fuse_gn it is applied in the conv's epilogue where the library can.  Stand-alone GroupNorms with no conv producer: the one after the stem and the skip halves of the
         decoder concats."""
         pg, B, L = self.pg, self.B, self.L
         cs, NE, R = m.channel_schedule, m.embed_cols, m.res_blocks

@@ -51,6 +51,7 @@ struct ConvArgs {
   char* gn_out;
   int32_t gn_ld, gn_off, gn_act, gn_cpg, gn_L;
   float gn_eps;
+  int32_t gn_tpe;  // persistent form: threads per (trajectory, group) sum
   int32_t debug;  // ablation bits for scripts/conv_bench.py: 1 = no loads after the first stage, 2 = no MFMA, 4 = no stores
   // split-K (register-staged kernel only): blockIdx.y = slice z computes K-steps [z * steps_per_split, ...) into partial[z][n][co]
   float* partial;
@@ -961,8 +962,9 @@ struct StreamCfg {
 //   epi_finish: transposes the accumulators through per-wave patches (16 rows x 64 channels, fp32) in released
 //     stage buffers and stores whole 128/256-byte row segments; no read of global memory is left in it, except the
 //     residual of 256-channel tiles (no registers to hold it during the K loop).
-template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_ROWS, bool PRE_RES, bool RES, bool EB, bool DIRECT_>
+template <typename T, int NI, int WCO, int TCH, int NWV, int EBT, bool PRE_ROWS, bool PRE_RES, bool RES, bool EB, bool DIRECT_, bool GNF_ = false>
 struct Epi {
+  static constexpr bool GNF = GNF_;
   // PRE_ROWS: the rows that get staged in LDS are read with the tile's first K-step (else in finish()); PRE_RES: so is the
   // residual.  Both are a question of register room in the K loop (scripts/check_spills.py).
   static constexpr bool PRE = PRE_ROWS;
@@ -987,6 +989,12 @@ struct Epi {
   // operation, and waiting for it waits for every DMA in flight).
   static __device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
+    return v;
+  }
+  // The lane index, recomputed from nothing (mbcnt): no register has to carry it across the K loop for the per-tile / per-segment code.
+  static __device__ __forceinline__ int fresh_lane() {
+    int v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v));
     return v;
   }
 
@@ -1022,7 +1030,7 @@ struct Epi {
   // embed rows; absent operands read a zero row instead of branching, so all loads are issued back to back) and, when
   // PRE_RES, the residual vectors.
   __device__ __forceinline__ void prefetch(const ConvArgs& p, int wave, int wr, int wc, int lane_, int n0, int co0) {
-    const int lane = opaque(lane_);
+    const int lane = fresh_lane();
     n_end = n0 + p.tile_rows < p.N ? n0 + p.tile_rows : p.N;
     b_first = fdiv(n0, p.div_m, p.div_k);
     ntraj = fdiv(n_end - 1, p.div_m, p.div_k) - b_first + 1;
@@ -1075,7 +1083,7 @@ struct Epi {
   }
   // bias + time-step row and the tile's per-trajectory embed rows: registers (prefetch) -> LDS
   __device__ __forceinline__ void stage_rows(uint32_t eb_lds, int wave, int lane_) {
-    const int tid_e = wave * 64 + opaque(lane_);
+    const int tid_e = wave * 64 + fresh_lane();
 #pragma unroll
     for (int k = 0; k < EBR; ++k) {
       const int idx = tid_e + k * NT;
@@ -1087,7 +1095,7 @@ struct Epi {
                                                 int n0, int co0) {
     constexpr int TP = VEC / 4, NPR = MI / TP;  // sub-tiles per 16-byte store, stores per sub-tile row
     static_assert(NPR == NQ * NP && NST == NI * NPR, "store count");
-    const int lane = opaque(lane_);
+    const int lane = fresh_lane();
     const int fr = lane & 15, fq = lane >> 4;
     const int cw = co0 + wc * WCO;  // first channel of this wave's tile
     if constexpr (!PRE) prefetch(p, wave, wr, wc, lane, n0, co0);
@@ -1187,6 +1195,225 @@ struct Epi {
     }
   }
 
+  // Direct epilogue with the CONSUMER's GroupNorm (+ activation) applied to the finished rows (p.gn_*): the persistent form of
+  // epilogue_lds<GN = true>.  Row tiles hold whole trajectories (p.tile_rows = k * lout, tiles start on a trajectory), and a channel
+  // tile holds whole groups, so every (trajectory, group) statistic is complete inside the workgroup.  The finished fp32 values stay
+  // in the accumulator registers; per-row group sums go through LDS (rs[group][row], in the window the K loop released) and are
+  // added per trajectory in a fixed order that depends only on the row's position INSIDE its trajectory: exact two-pass statistics
+  // (mean, then centred squares), bitwise reproducible and independent of how the batch is cut into tiles or shards.  No atomics.
+  //   rs_lds : GT x 256 floats (GT = TCH / cpg groups per channel tile);  tab_lds : mean[E] | rstd[E], E = (tile_rows / lout) * GT <= 1024
+  //   (its own 8 KB); gb_lds : gamma[0 .. cout) at +0, beta at +4096 (staged once per workgroup at kernel start).
+  template <int MI>
+  __device__ __forceinline__ void finish_direct_gn(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t eb_lds, uint32_t rs_lds, uint32_t tab_lds,
+                                                   uint32_t gb_lds, int wave, int wr, int wc, int lane_, int n0, int co0) {
+    constexpr int TP = VEC / 4, NPR = MI / TP;
+    static_assert(VEC == 8 && NPR == NQ * NP && NST == NI * NPR, "bf16 direct layout");
+    typedef __attribute__((address_space(3))) float lds_f32_t;
+    const int lane = fresh_lane();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cw = co0 + wc * WCO;
+    if constexpr (!PRE) prefetch(p, wave, wr, wc, lane, n0, co0);
+    // residual vectors that were not prefetched with the tile's first K-step (256-channel tiles): one sub-tile row ahead of their use,
+    // 2 x NPR vectors live instead of all NI x NPR (with the 128 finished values in registers there is no room for more: a spill here
+    // means scratch memory, and a kernel that needs scratch is not something to put into a replayed graph lightly)
+    constexpr bool LATE_RES = RES && !PRE_RES;
+    u32x4 rnext[LATE_RES ? NPR : 1];
+    auto res_row = [&](int ni, u32x4 (&dst)[LATE_RES ? NPR : 1]) {
+      const int n = n0 + wr * 64 + ni * 16 + fr;
+#pragma unroll
+      for (int P = 0; P < (LATE_RES ? NPR : 0); ++P) {
+        const int co = co0 + wc * WCO + P * 4 * VEC + fq * VEC;
+        dst[P] = (n < n_end && co < p.cout) ? *reinterpret_cast<const u32x4*>(p.res + ((size_t)n * p.res_ld + co) * ES) : (u32x4){0u, 0u, 0u, 0u};
+      }
+    };
+    if constexpr (LATE_RES) res_row(0, rnext);
+    const bool raw = p.out != nullptr;
+    const size_t obase = ((size_t)n0 * p.out_ld + p.out_off + cw) * ES;
+    const size_t oleft = raw ? (size_t)p.N * p.out_ld * ES - obase : 0;
+    const u32x4 rsrc_o = make_srd(raw ? p.out + obase : p.gn_out, oleft > 0x7fffffffull ? 0x7fffffffu : (uint32_t)oleft);
+    const size_t gbase = ((size_t)n0 * p.gn_ld + p.gn_off + cw) * ES;
+    const size_t gleft = (size_t)p.N * p.gn_ld * ES - gbase;
+    const u32x4 rsrc_g = make_srd(p.gn_out + gbase, gleft > 0x7fffffffull ? 0x7fffffffu : (uint32_t)gleft);
+    __syncthreads();  // every wave is done with the K loop's last buffers: the staged rows and the statistics go there
+    stage_rows(eb_lds, wave, lane);
+    __syncthreads();
+    const bool eb_lds_on = EB && p.ebias && eb_staged;
+    const int ch0 = wc * WCO + fq * VEC;
+    // ---- finished values (bias, embed rows, activation, residual) back into the accumulator registers; raw rows stored if wanted ----
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row_local = wr * 64 + ni * 16 + fr;
+      const int n = n0 + row_local;
+      uint32_t eb_row = 0;
+      if constexpr (EB) if (eb_lds_on) {
+        const int t = fdiv(n < n_end ? n : n_end - 1, p.div_m, p.div_k) - b_first;
+        eb_row = eb_lds + ((1 + t) * TCH + ch0) * 4;
+      }
+      u32x4 rcur[LATE_RES ? NPR : 1];
+      if constexpr (LATE_RES) {
+#pragma unroll
+        for (int P = 0; P < NPR; ++P) rcur[P] = rnext[P];
+        if (ni + 1 < NI) res_row(ni + 1, rnext);
+      }
+#pragma unroll
+      for (int P = 0; P < NPR; ++P) {
+        const int chl = ch0 + P * 4 * VEC;
+        const bool live = n < n_end && co0 + chl < p.cout;
+        float v[VEC];
+#pragma unroll
+        for (int h = 0; h < TP; ++h) {
+          const f32x4 bs = lds_ld16(eb_lds + (chl + h * 4) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[h * 4 + j] = acc[P * TP + h][ni][j] + bs[j];
+        }
+        if constexpr (EB) {
+          if (eb_lds_on) {
+#pragma unroll
+            for (int h = 0; h < TP; ++h) {
+              const f32x4 e = lds_ld16(eb_row + (P * 4 * VEC + h * 4) * 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[h * 4 + j] += e[j];
+            }
+          } else if (p.ebias && live) {
+            const int bb = fdiv(n, p.div_m, p.div_k);
+            const float* e = p.ebias + (size_t)bb * p.ebias_ld + p.ebias_off + co0 + chl;
+#pragma unroll
+            for (int h = 0; h < TP; ++h) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(e + h * 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[h * 4 + j] += t[j];
+            }
+          }
+        }
+        if (p.act == TDX_ACT_SWISH) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = tdx_swish(v[j]);
+        } else if (p.act == TDX_ACT_LEAKY) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = tdx_leaky(v[j]);
+        }
+        if constexpr (RES) {
+          float rv[VEC];
+          if constexpr (LATE_RES) Elem<T>::unpack(rcur[P], rv);
+          else Elem<T>::unpack(resv[ni][P / NP][P % NP], rv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += rv[j];
+        }
+        buf_store16(Elem<T>::pack(v), live && raw ? (uint32_t)(row_local * p.out_ld + P * 4 * VEC + fq * VEC) * ES : kOob, rsrc_o);
+#pragma unroll
+        for (int h = 0; h < TP; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[P * TP + h][ni][j] = live ? v[h * 4 + j] : 0.f;
+      }
+    }
+    // ---- statistics ----
+    const int cpg = p.gn_cpg;                       // 8, 16, 32 or 64 channels per group
+    const int cps = __builtin_ctz((unsigned)cpg);   // (powers of two: shifts instead of integer divisions)
+    const int GT = TCH >> cps, gts = __builtin_ctz((unsigned)GT);
+    const int lsh = cpg >= 32 ? 2 : (cpg >= 16 ? 1 : 0);   // a group spans 1 << lsh lanes (fq) of a row
+    const bool pairP = cpg == 64;                   // ... and two 32-channel chunks
+    const bool writer = (fq & ((1 << lsh) - 1)) == 0;
+    const int L = p.gn_L;
+    const int E = (p.tile_rows / L) * GT;
+    const int tpe = p.gn_tpe;                       // power of two <= 16: threads that share one (trajectory, group) sum
+    const int tid = wave * 64 + lane;
+    const float inv_cnt = 1.0f / ((float)cpg * (float)L);
+    auto lane_sum = [&](float s) {
+      if (lsh >= 1) s += __shfl_xor(s, 16, 64);
+      if (lsh >= 2) s += __shfl_xor(s, 32, 64);
+      return s;
+    };
+    // rs[g][row] <- per-row group sums of f(value); then tab[e] <- fin(sum over the trajectory's rows * inv_cnt)
+    auto reduce_rows = [&](uint32_t tab, auto fin) {
+      const int tps = __builtin_ctz((unsigned)tpe);
+      const int sub = tid & (tpe - 1), per_round = NT >> tps;
+      for (int e0 = 0; e0 < E; e0 += per_round) {
+        const int e = e0 + (tid >> tps);
+        float sum = 0.f;
+        if (e < E) {
+          const int traj = e >> gts, g = e & (GT - 1);
+          const uint32_t base = rs_lds + (uint32_t)(g * 256 + traj * L) * 4;
+          for (int l = sub; l < L; l += tpe) sum += *reinterpret_cast<lds_f32_t*>(base + l * 4);
+        }
+        for (int o = 1; o < tpe; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        if (e < E && sub == 0) *reinterpret_cast<lds_f32_t*>(tab + e * 4) = fin(sum * inv_cnt);
+      }
+    };
+    // trajectory (inside the tile) of each of this lane's four rows, and the group of each channel chunk
+    int trow[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wr * 64 + ni * 16 + fr;
+      trow[ni] = fdiv(n < n_end ? n : n_end - 1, p.div_m, p.div_k) - b_first;
+    }
+    const uint32_t tab_mean = tab_lds, tab_rstd = tab_lds + (uint32_t)E * 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row_local = wr * 64 + ni * 16 + fr;
+        float sp[NPR];
+#pragma unroll
+        for (int P = 0; P < NPR; ++P) {
+          const int g = (ch0 + P * 4 * VEC) >> cps;
+          const float m = pass ? *reinterpret_cast<lds_f32_t*>(tab_mean + (trow[ni] * GT + g) * 4) : 0.f;
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = acc[P * TP][ni][j] - m, b = acc[P * TP + 1][ni][j] - m;
+            s0 += pass ? a * a : a;
+            s1 += pass ? b * b : b;
+          }
+          sp[P] = s0 + s1;
+        }
+#pragma unroll
+        for (int P = 0; P < NPR; ++P) {
+          if (pairP && (P & 1)) continue;
+          const float s = lane_sum(pairP ? sp[P] + sp[P + 1 < NPR ? P + 1 : P] : sp[P]);
+          const int g = (ch0 + P * 4 * VEC) >> cps;
+          if (writer) *reinterpret_cast<lds_f32_t*>(rs_lds + (uint32_t)(g * 256 + row_local) * 4) = s;
+        }
+      }
+      __syncthreads();
+      const float eps = p.gn_eps;
+      if (pass == 0) reduce_rows(tab_mean, [](float x) { return x; });
+      else reduce_rows(tab_rstd, [eps](float x) { return rsqrtf(x + eps); });
+      __syncthreads();
+    }
+    // ---- normalise, activate, store ----
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row_local = wr * 64 + ni * 16 + fr;
+      const int n = n0 + row_local;
+#pragma unroll
+      for (int P = 0; P < NPR; ++P) {
+        const int chl = ch0 + P * 4 * VEC;
+        const bool live = n < n_end && co0 + chl < p.cout;
+        const int g = chl >> cps;
+        const float m = *reinterpret_cast<lds_f32_t*>(tab_mean + (trow[ni] * GT + g) * 4);
+        const float q = *reinterpret_cast<lds_f32_t*>(tab_rstd + (trow[ni] * GT + g) * 4);
+        float y[VEC];
+#pragma unroll
+        for (int h = 0; h < TP; ++h) {
+          const f32x4 gm = lds_ld16(gb_lds + (co0 + chl + h * 4) * 4), bt = lds_ld16(gb_lds + 4096 + (co0 + chl + h * 4) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float sc = q * gm[j];
+            y[h * 4 + j] = fmaf(acc[P * TP + h][ni][j], sc, bt[j] - m * sc);
+          }
+        }
+        if (p.gn_act == TDX_ACT_SWISH) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) y[j] = tdx_swish(y[j]);
+        } else if (p.gn_act == TDX_ACT_LEAKY) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) y[j] = tdx_leaky(y[j]);
+        }
+        buf_store16(Elem<T>::pack(y), live ? (uint32_t)(row_local * p.gn_ld + P * 4 * VEC + fq * VEC) * ES : kOob, rsrc_g);
+      }
+    }
+  }
+
   // patch: LDS address of this wave's two pieces; eb_lds: LDS address of the staged rows.
   template <int MI>
   __device__ __forceinline__ void finish(const ConvArgs& p, f32x4 (&acc)[MI][NI], uint32_t patch, uint32_t eb_lds, int wave, int wr, int wc,
@@ -1196,7 +1423,7 @@ struct Epi {
       finish_direct(p, acc, eb_lds, wave, wr, wc, lane_, n0, co0);
       return;
     }
-    const int lane = opaque(lane_);
+    const int lane = fresh_lane();
     const int fr = lane & 15, fq = lane >> 4;
     const int c = lane % CPR, r0 = lane / CPR;
     const int cw = co0 + wc * WCO;  // first channel of this wave's tile
@@ -1308,7 +1535,10 @@ struct Epi {
 };
 
 // MODE: 0 = no per-trajectory embed rows and no residual, 1 = embed rows, 2 = residual (both at once: one-tile kernel).
-template <typename T, int TC, int TR, bool WIN, int MODE>
+// GNF: the consumer's GroupNorm (+ activation) in the epilogue (Epi::finish_direct_gn; bf16 window kernels with 256-row tiles).
+constexpr int kGnTabMax = 1024;              // (trajectory, group) statistics per tile
+constexpr int kGnLds = 8192 + 8192 + 64;     // gamma | beta of up to 1024 output channels, mean | rstd tables, behind the (diagnostic) stamp words
+template <typename T, int TC, int TR, bool WIN, int MODE, bool GNF = false>
 __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs p) {
   constexpr bool RES = MODE == 2, EB = MODE == 1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1350,7 +1580,18 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
   if (!tile_of(jt, cp_n0, cp_co0)) return;
 
   // (the gathered 256-channel tiles keep the transposing epilogue: no register room for the direct one, scripts/check_spills.py)
-  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, TC == 128 || WIN, TC == 128, RES, EB, TDX_DIRECT_EPI && (WIN || TC == 128)>;
+  // (GroupNorm epilogue on 256-channel tiles with a residual: the staged rows are read in the epilogue, where the residual loads
+  //  already wait for the next tile's first DMAs, instead of across the K loop: the registers they would hold there are not free)
+  using EpiT = Epi<T, 4, TC / 2, TC, NW, Cfg::EBT, (TC == 128 || WIN) && !(GNF && RES && TC == 256), TC == 128, RES, EB, TDX_DIRECT_EPI && (WIN || TC == 128), GNF>;
+  static_assert(!GNF || (EpiT::DIRECT && WIN && TR == 256 && sizeof(T) == 2), "fused GroupNorm: bf16 window kernels with 256-row tiles");
+  const uint32_t gb_lds = lds_base + (uint32_t)(W_BASE + 2 * kWinBytes + 64);
+  if constexpr (GNF) {   // gamma | beta of every output channel, once per workgroup (before any DMA is in flight)
+    typedef __attribute__((address_space(3))) float lds_f32_t;
+    for (int i = tid; i < p.cout; i += TR * 2) {
+      *reinterpret_cast<lds_f32_t*>(gb_lds + i * 4) = p.gn_gamma[i];
+      *reinterpret_cast<lds_f32_t*>(gb_lds + 4096 + i * 4) = p.gn_beta[i];
+    }
+  }
   // ---- loader state (always one K-step ahead of the MFMAs, also across tile boundaries) ------------------------
   int ld_n0 = 0;
   u32x4 rsrc_a, rsrc_b;
@@ -1385,7 +1626,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     ld_cin = s.cin;
     const int pad = s.taps == 3 ? 1 : 0;
     // (recomputed from the lane index here, once per segment, rather than kept in a register across the K loop)
-    const int lane_o = EpiT::opaque(lane);
+    const int lane_o = EpiT::fresh_lane();
     const uint32_t chunk_off = (uint32_t)(((lane_o & 7) ^ (lane_o >> 3)) << 4);
     if constexpr (WIN) {
       const int base_row = ld_n0 - pad > 0 ? ld_n0 - pad : 0;
@@ -1394,7 +1635,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       rsrc_b = make_srd(s.src + base, left > 0x7fffffffull ? 0x7fffffffu : (uint32_t)left);
       // window row j of the tile = source row n0 - pad + j; row -1 (first tile) wraps to a huge offset, rows >= N lie
       // beyond num_records: both are out of range for the DMA, which then writes zeros
-      voff_w0 = (uint32_t)((ld_n0 - pad - base_row + 8 * wave + EpiT::opaque(r8)) * s.src_ld * ES) + chunk_off;
+      voff_w0 = (uint32_t)((ld_n0 - pad - base_row + 8 * wave + (lane_o >> 3)) * s.src_ld * ES) + chunk_off;
       stride_w = (uint32_t)(8 * NW * s.src_ld * ES);
     } else {
       const int b0 = fdiv(ld_n0, p.div_m, p.div_k);
@@ -1421,7 +1662,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
     ld_seg = ld_ci = ld_tap = 0;
     if constexpr (!WIN) {
       const int b0 = fdiv(n0, p.div_m, p.div_k);
-      const int r8_o = EpiT::opaque(r8);
+      const int r8_o = EpiT::fresh_lane() >> 3;
 #pragma unroll
       for (int i = 0; i < GB; ++i) {
         const int i_loc = 8 * (wave + NW * i) + r8_o;
@@ -1498,7 +1739,7 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     cp_seg = cp_ci = cp_tap = 0;
     if constexpr (WIN) {
-      const int fr_o = EpiT::opaque(fr);  // (keeps the per-tile index math out of the registers that live across the K loop)
+      const int fr_o = EpiT::fresh_lane() & 15;  // (keeps the per-tile index math out of the registers that live across the K loop)
       wm3 = wm1 = 0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -1585,7 +1826,9 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
 #if TDX_STAMPS
     const uint32_t st0 = st_now();
 #endif
-    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::NST) : "memory");  // first step of a tile: DMAs landed, stores may still drain
+    // first step of a tile: DMAs landed, stores may still drain (GroupNorm epilogue: a raw and a normalised store per item, the raw ones
+    // with every lane out of range when nobody wants the raw rows: the count stays a constant of the kernel)
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GNF ? 2 : 1) * Cfg::NST) : "memory");
     else wait_vm(cp_tap == 0 ? 0 : pend_w);  // (a block's first step needs its window)
     counted = false;
 #if TDX_STAMPS
@@ -1694,7 +1937,12 @@ __global__ __launch_bounds__(TR * 2) void conv_gemm_stream_kernel(const ConvArgs
 #if TDX_STAMPS
     const uint32_t sb1 = st_now();
 #endif
-    epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
+    if constexpr (GNF) {
+      const uint32_t scr_w = lds_base + W_BASE + ((blk - 1) & 1) * kWinBytes;
+      epi.finish_direct_gn(p, acc, eb, scr_w, gb_lds + 8192u, gb_lds, wave, wr, wc, lane, cp_n0, cp_co0);
+    } else {
+      epi.finish(p, acc, patch, eb, wave, wr, wc, lane, cp_n0, cp_co0);
+    }
 #if TDX_STAMPS
     {
       const uint32_t sb2 = st_now();
@@ -1755,7 +2003,7 @@ int dispatch_dma(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, bo
   return tc == 256 ? launch_dma<T, 256, 256, false, false>(a, st) : launch_dma<T, 128, 256, false, false>(a, st);
 }
 
-template <typename T, int TC, int TR, bool WIN, int MODE>
+template <typename T, int TC, int TR, bool WIN, int MODE, bool GNF = false>
 int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   const int nco = (a.cout + TC - 1) / TC;
   const int jt_end = nco * ((a.row_tiles + 7) / 8);
@@ -1763,14 +2011,15 @@ int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   const int nslot = jt_end < per_xcd ? jt_end : per_xcd;
   size_t lds = dma_lds_bytes(TC, TR, WIN);
   if (TDX_STAMPS) lds += 64;
+  if (GNF) lds = dma_lds_bytes(TC, TR, WIN) + kGnLds;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, MODE, GNF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       TDX_FAIL(TDX_ERR_HIP, "conv_gemm_stream: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN, MODE>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_stream_kernel<T, TC, TR, WIN, MODE, GNF>), dim3((unsigned)(8 * nslot)), dim3(TR * 2), lds, st, a);
   TDX_CHECK_LAUNCH("conv_gemm_stream_kernel");
   return TDX_OK;
 }
@@ -1797,6 +2046,16 @@ int launch_stream(const ConvArgs& a, hipStream_t st, int cus) {
   TDX_FAIL(TDX_ERR_UNSUPPORTED, "conv_gemm_stream: internal dispatch error (tc=%d win=%d mode=%d)", TC, (int)WIN, mode);
 }
 
+// Persistent kernel with the fused GroupNorm epilogue: bf16, window mode, 256-row tiles (plan_conv / gn_stream_ok decide).
+template <int TC>
+int launch_stream_gn(const ConvArgs& a, hipStream_t st, int cus) {
+  const int mode = conv_mode(a);
+  if (mode == 0) return launch_stream2<__bf16, TC, 256, true, 0, true>(a, st, cus);
+  if (mode == 1) return launch_stream2<__bf16, TC, 256, true, 1, true>(a, st, cus);
+  if (mode == 2) return launch_stream2<__bf16, TC, 256, true, 2, true>(a, st, cus);
+  TDX_FAIL(TDX_ERR_UNSUPPORTED, "conv_gemm_stream (GroupNorm epilogue): embed rows together with a residual");
+}
+
 template <typename T>
 int dispatch_stream(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win, int cus) {
   if (tr == 128) return win ? launch_stream<T, 128, 128, true>(a, st, cus) : launch_stream<T, 128, 128, false>(a, st, cus);
@@ -1808,7 +2067,7 @@ int dispatch_stream(const ConvArgs& a, hipStream_t st, int tc, int tr, bool win,
 
 // Validate a descriptor, translate it to kernel arguments and choose the kernel.  kind: 0 = register-staged
 // 128x128, 1 = LDS-DMA gather, 2 = LDS-DMA window; tc = channel tile of the DMA kernels; gn = fused GroupNorm.
-struct Choice { int kind, tc, tr; bool gn; };
+struct Choice { int kind, tc, tr; bool gn; bool gn_stream = false; };
 
 static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
   TDX_CHECK_ARG(d != nullptr, "tdx_conv_gemm: null descriptor");
@@ -1903,7 +2162,19 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
     const int cpg = d->gn_cpg;
     bool ok = dma_ok && !(g_force & 4) && d->lout <= kDmaRows && cpg >= 4 && cpg >= vec / 2 && (cpg & (cpg - 1)) == 0 && cpg <= tc / 2 &&
               d->gn_off % vec == 0 && d->gn_ld % vec == 0 && d->gn_off + d->cout <= d->gn_ld;
-    ok = ok && gn_lds_bytes(tc, cpg, d->lout) <= dma_lds_bytes(tc, 256, win_ok);
+    // Persistent form (Epi::finish_direct_gn): bf16 window convs, groups of 8 .. 64 channels inside one wave's half of the channel tile,
+    // statistics tables that fit the scratch the K loop releases.  Everything else that is fusable takes the one-tile kernel.
+    bool gs = ok && !(g_force & 32) && win_ok && d->dtype == TDX_BF16 && cpg >= 8 && cpg <= 64 && d->cout <= 1024 && !(d->res && d->ebias) &&
+              d->gn_off % 8 == 0 && d->gn_ld % 8 == 0 && (int64_t)(kDmaRows + 16) * d->gn_ld * es < (1ll << 31);
+    // (the statistics tables of a tile: judged for 256-channel tiles whatever the tile chosen below, so that the answer depends on the
+    //  layer's shape alone and never on the batch size: batch shards must take the same arithmetic as the unsharded batch)
+    gs = gs && (kDmaRows / d->lout) * (256 / cpg) <= kGnTabMax;
+    if (gs) {
+      // threads that share one (trajectory, group) row sum: a function of the trajectory length ALONE, so that the order of the
+      // additions does not depend on the batch size or the tile shape (batch shards reproduce the unsharded run bit for bit)
+      a.gn_tpe = d->lout >= 32 ? 8 : (d->lout >= 8 ? 4 : (d->lout >= 4 ? 2 : 1));
+    }
+    ok = ok && (gs || gn_lds_bytes(tc, cpg, d->lout) <= dma_lds_bytes(tc, 256, win_ok));
     if (!ok) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_conv_gemm: this shape cannot fuse the GroupNorm (lout=%d cout=%d cpg=%d): run tdx_groupnorm_act", d->lout, d->cout, cpg);
     a.tile_rows = (kDmaRows / d->lout) * d->lout;
     a.gn_gamma = d->gn_gamma;
@@ -1914,7 +2185,7 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
     a.gn_act = d->gn_act;
     a.gn_cpg = cpg;
     a.gn_eps = d->gn_eps;
-    ch = Choice{win_ok ? 2 : 1, tc, 256, true};
+    ch = Choice{win_ok ? 2 : 1, tc, 256, true, gs};
   } else if (dma_ok && tiles >= 128) {
     ch = Choice{win_ok ? 2 : 1, tc, tr, false};
     a.tile_rows = tr;
@@ -1942,7 +2213,10 @@ static int cu_count() {
 template <typename T>
 static int run_dma(ConvArgs& a, const Choice& ch, hipStream_t st) {
   const bool win = ch.kind == 2;
-  // Persistent kernel for every tile shape; the GroupNorm epilogue exists in the one-tile-per-workgroup form only.
+  if constexpr (sizeof(T) == 2) {
+    if (ch.gn && ch.gn_stream) return ch.tc == 256 ? launch_stream_gn<256>(a, st, cu_count()) : launch_stream_gn<128>(a, st, cu_count());
+  }
+  // Persistent kernel for every tile shape; the general GroupNorm epilogue exists in the one-tile-per-workgroup form only.
   const bool stream = !ch.gn && !(g_force & 32);
   auto go = [&](const ConvArgs& x, int tc, int tr) {
     return stream && stream_ok<T>(tc, win, conv_mode(x)) ? dispatch_stream<T>(x, st, tc, tr, win, cu_count())
@@ -1982,7 +2256,7 @@ extern "C" int tdx_conv_gemm_stamps(void* ptr) {
 extern "C" int tdx_conv_gemm_gn_fusable(const tdx_conv_desc* d) {
   ConvArgs a;
   Choice ch;
-  return d && d->gn_gamma && plan_conv(d, a, ch) == TDX_OK && ch.gn ? 1 : 0;
+  return d && d->gn_gamma && plan_conv(d, a, ch) == TDX_OK && ch.gn ? (ch.gn_stream ? 2 : 1) : 0;
 }
 
 extern "C" int tdx_conv_gemm(const tdx_conv_desc* d, void* stream) {

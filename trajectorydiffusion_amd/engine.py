@@ -8,6 +8,7 @@ the path is a call into libtrajdiff_hip.so (trajectorydiffusion_amd/_lib.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -16,7 +17,20 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_SWISH, ConvDesc, TdxError
 
 
-FUSE_GN_DEFAULT = False
+# GroupNorm(+Swish) of a conv's consumer inside the conv's epilogue (tdx_conv_desc.gn_*):
+#   False  never: every GroupNorm is a stand-alone tdx_groupnorm_act pass;
+#   True   wherever the library can (both kernel forms; the ablation / test setting);
+#   "auto" the persistent kernel's form only (tdx_conv_gemm_gn_fusable() == 2), for convs whose raw output nobody reads and whose
+#          trajectories fill >= 93 % of a 256-row tile.
+# Measured on MI355X, round 3 (profiles/r3_gn_per_layer_ablation.txt, profiles/r3_c5_gn_fusion.txt):
+#   TrajUNet (B = 2048 per launch): the pass wins or ties on every layer.  The fused epilogue costs what the pass costs (the Swish of
+#   128 values per lane, the statistics' LDS round trips and a second store sweep sit in series with the K loop, while the pass runs
+#   at copy rate), and tiles of whole trajectories cannot use the small-tile tail launch (820 tiles = 4 rounds instead of 3.125).
+#   SDUNet_CAR (3 .. 24 rows per trajectory, launch-latency-sized GroupNorm passes): "auto" is 1.9 % faster per denoise step.
+# Hence: False by default, SDUNet_CAR asks for "auto" (Program.fuse_gn).  TDX_FUSE_GN=0|1|auto in the environment overrides both.
+FUSE_GN_ENV = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("TDX_FUSE_GN", ""), None)
+FUSE_GN_DEFAULT = False if FUSE_GN_ENV is None else FUSE_GN_ENV
+FUSE_GN_MIN_FILL = 0.93
 # Split GroupNorm on the full-resolution 128-channel level (bf16 programs): producers leave block partial sums (stats_out),
 # tdx_groupnorm_finalize turns them into {rstd, -mean * rstd}, and the consuming conv normalises + activates its input while it
 # loads it (tdx_conv_desc.norm): no stand-alone GroupNorm pass and no normalised copy of those activations in memory.
@@ -181,7 +195,11 @@ class Program:
         if gn is not None:
             d.gn_gamma, d.gn_beta = gn.gamma.data_ptr() + 4 * gn.p_off, gn.beta.data_ptr() + 4 * gn.p_off
             d.gn_out, d.gn_ld, d.gn_off, d.gn_act, d.gn_cpg, d.gn_eps = gn.out.data_ptr(), gn.out_ld, gn.out_off, gn.act, gn.cpg, gn.eps
-            fused = self.fuse_gn and bool(self.lib.tdx_conv_gemm_gn_fusable(C.byref(d)))
+            form = int(self.lib.tdx_conv_gemm_gn_fusable(C.byref(d))) if self.fuse_gn else 0
+            if self.fuse_gn == "auto":
+                fused = form == 2 and out is None and (256 // lout) * lout >= FUSE_GN_MIN_FILL * 256
+            else:
+                fused = form > 0
             if not fused:
                 d.gn_gamma = None
                 if out is None:  # the separate GroupNorm kernel needs the raw tensor

@@ -80,6 +80,24 @@ class GraphSampler:
         self.graphs = {}
         self.first_elem = 0
 
+    def close(self) -> None:
+        """Drop the captured graphs at a defined point: after everything they may still be executing has finished, and never from inside
+        another stream capture (DiffusionManager.release_samplers calls this when a sampler is replaced; a sampler that the cyclic
+        garbage collector frees at some arbitrary later moment is what round 3 saw crash the host inside a later hipGraphLaunch)."""
+        if self.graphs:
+            try:
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize(self.device)
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
+            self.graphs.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
     def valid(self) -> bool:
         """False when the model dropped this sampler's programs (parameters moved, dtype/mode changed).  Weight VALUES may
         change freely: the packed copies are refreshed in place (also after writes through `.data`, which only the norm
@@ -142,6 +160,20 @@ class GraphSampler:
         if tuple(x_T.shape) != (self.B, self.D, self.L):
             raise TdxError(f"sampler built for {(self.B, self.D, self.L)}, got x_T {tuple(x_T.shape)}")
         inject = noise is not None and not self.ddim
+        # Garbage that holds captured graphs or device buffers (programs of dropped models, replaced samplers: they sit in reference
+        # cycles) is destroyed HERE, at a defined point, and the cyclic collector stays off while graphs are captured and replayed:
+        # round 3 saw a host-side crash inside hipGraphLaunch that went away once no destructor could run in the middle of the loop.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._sample(x_T, cat_attr, num_attr, noise, inject, first_sample, use_graph, trace)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _sample(self, x_T, cat_attr, num_attr, noise, inject, first_sample, use_graph, trace) -> torch.Tensor:
         self.first_elem = int(first_sample) * self.D * self.L
         for sh in self.shards:
             sh.first_elem = (int(first_sample) + sh.lo) * self.D * self.L

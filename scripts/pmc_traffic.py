@@ -37,7 +37,10 @@ gn_rd = 2 * raw["FETCH_SIZE"]["groupnorm_act"]["sum_KiB"] * 1024 / steps
 gn_wr = raw["WRITE_SIZE"]["groupnorm_act"]["sum_KiB"] * 1024 / steps
 B = int(workload.split("B=")[1].split(",")[0])
 es = 2 if "bf16" in workload else 4
+import datetime
+import socket
 res = {
+    "measured_on": "%s, host %s (scripts/profile_round.sh)" % (datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M UTC"), socket.gethostname()),
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --T 3 --no-cpu-baseline --no-graph",
     "workload": workload, "slices_per_denoise_step": SLICES, "raw": raw, "denoise_steps_covered": steps,
     "gfx950_correction": "FETCH_SIZE doubled; calibration on groupnorm_act: 2*FETCH = %.2f GB/step, WRITE = %.2f GB/step vs %.2f GB algorithmic each"

@@ -27,12 +27,16 @@ class _PackedModel(_HipBlock):
         return sum(p._version for p in ps), tuple(p.data_ptr() for p in ps)
 
     def _data_digest(self) -> Optional[torch.Tensor]:
-        """Per-parameter L2 norms on the device: compared against the norms the cached GEMM-layout copies were built from,
-        this catches weight updates that no version counter sees.  One pass over the weights, no host sync of its own."""
-        ps = [p.detach() for p in self.parameters()]
+        """Three figures per parameter AND floating-point buffer (BatchNorm running statistics), on the device: L2 norm, sum, and the
+        sum of the odd-indexed elements.  Compared against the figures the cached GEMM-layout copies were built from, this catches
+        weight updates that no version counter sees, including ones that keep a tensor's norm (sign flips, most permutations, swaps of
+        equal-norm tensors change the sums).  Not a cryptographic check: a write that preserves all three figures of every tensor goes
+        unseen, and invalidate() is the explicit way.  A few passes over the weights, no host sync of its own."""
+        ps = [p.detach() for p in self.parameters()] + [b.detach() for b in self.buffers() if b.is_floating_point()]
         if not ps or not all(p.is_cuda for p in ps):
             return None
-        return torch.stack(torch._foreach_norm(ps))
+        flat = [p.reshape(-1).float() for p in ps]
+        return torch.cat([torch.stack(torch._foreach_norm(flat)), torch.stack([f.sum() for f in flat]), torch.stack([f[1::2].sum() for f in flat])])
 
     def invalidate(self):
         """Force the cached GEMM-layout weight copies to be refreshed before the next forward / sampling call.  Needed only

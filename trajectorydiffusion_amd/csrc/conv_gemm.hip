@@ -605,7 +605,8 @@ int launch(const ConvArgs& a, hipStream_t st) {
   const int nco = (a.cout + TC - 1) / TC, nrow = (a.N + TR - 1) / TR;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
   size_t lds = 2 * (size_t)(TR + TC) * kRowBytes;
-  static bool attr_done = false;
+  static bool attr_done_dev[kTdxMaxDevices] = {};   // (per device: hipFuncSetAttribute acts on the current device's copy of the kernel)
+  bool& attr_done = attr_done_dev[tdx_device_slot()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TR, TC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1980,7 +1981,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   const int nco = (a.cout + TC - 1) / TC, nrow = a.row_tiles;
   dim3 grid((unsigned)(nco * ((nrow + 7) / 8) * 8));
   size_t lds = dma_lds_bytes(TC, TR, WIN);
-  static bool attr_done = false;
+  static bool attr_done_dev[kTdxMaxDevices] = {};   // (per device: hipFuncSetAttribute acts on the current device's copy of the kernel)
+  bool& attr_done = attr_done_dev[tdx_device_slot()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<T, TC, TR, WIN, GN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -2012,7 +2014,8 @@ int launch_stream2(const ConvArgs& a, hipStream_t st, int cus) {
   size_t lds = dma_lds_bytes(TC, TR, WIN);
   if (TDX_STAMPS) lds += 64;
   if (GNF) lds = dma_lds_bytes(TC, TR, WIN) + kGnLds;
-  static bool attr_done = false;
+  static bool attr_done_dev[kTdxMaxDevices] = {};   // (per device: hipFuncSetAttribute acts on the current device's copy of the kernel)
+  bool& attr_done = attr_done_dev[tdx_device_slot()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_stream_kernel<T, TC, TR, WIN, MODE, GNF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -2201,7 +2204,8 @@ static int plan_conv(const tdx_conv_desc* d, ConvArgs& a, Choice& ch) {
 
 // Workgroup slots of 256-row tiles (one 8-wave workgroup per CU).
 static int cu_count() {
-  static int n = 0;
+  static int n_dev[kTdxMaxDevices] = {};   // per device
+  int& n = n_dev[tdx_device_slot()];
   if (n == 0) {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;

@@ -465,7 +465,8 @@ extern "C" int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, 
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)((B + tb - 1) / tb));
   if (dtype == TDX_F32) {
-    static bool attr = false;
+    static bool attr_dev[kTdxMaxDevices] = {};
+    bool& attr = attr_dev[tdx_device_slot()];
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
         TDX_FAIL(TDX_ERR_HIP, "tdx_cross_attention: cannot reserve LDS");
@@ -474,7 +475,8 @@ extern "C" int tdx_cross_attention(const void* q, int32_t q_ld, const void* kv, 
     hipLaunchKernelGGL(cross_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)q, q_ld, (const float*)kv, kv_ld, (long)kv_bs, (float*)out,
                        out_ld, B, L, N, C, tb, scale);
   } else {
-    static bool attr = false;
+    static bool attr_dev[kTdxMaxDevices] = {};
+    bool& attr = attr_dev[tdx_device_slot()];
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attention_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
         TDX_FAIL(TDX_ERR_HIP, "tdx_cross_attention: cannot reserve LDS");

@@ -38,7 +38,8 @@ namespace {
 // 64-channel blocks of 128-byte rows with conv_gemm.hip's XOR swizzle, each followed by one permanently-zero row), the residual
 // rows (RES), the tile's per-trajectory embed rows and its {rstd, -mean * rstd} rows.  The loop body contains no other load.
 constexpr int kTileRows = 64;                    // output (padded) rows per tile
-constexpr int kMaxTraj = 4;                      // trajectories a tile may touch (64 padded rows, Lp >= 32: at most 3)
+constexpr int kMaxTraj = 4;                      // trajectories a tile may touch: 64 padded rows of trajectories of Lp >= 32 padded rows start in at
+                                                 // most 3 of them; the host gate (narrow_plan: tr / lp + 2 <= kMaxTraj) keeps one in hand
 constexpr int kMrBytes = kMaxTraj * 32 * 8;      // {rstd, -mean * rstd} per (trajectory, group)
 constexpr int kEbBytes = kMaxTraj * 128 * 4;     // per-trajectory embed rows
 constexpr int kResBytes = kTileRows * 256;       // residual rows of the tile (16-byte chunks XOR-swizzled by the row)
@@ -541,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void narrow_conv_kernel(const NarrowArgs p)
 template <int MODE, bool NORM, bool STATS, bool RES>
 int launch_narrow(const NarrowArgs& a, hipStream_t st, int cus) {
   constexpr int kLds = lds_bytes<MODE, RES>();
-  static bool attr_done = false;
+  static bool attr_done_dev[kTdxMaxDevices] = {};   // (per device: hipFuncSetAttribute acts on the current device's copy of the kernel)
+  bool& attr_done = attr_done_dev[tdx_device_slot()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_conv_kernel<MODE, NORM, STATS, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLds) != hipSuccess)
@@ -574,8 +576,8 @@ void magic(int d, uint64_t& m, int& k) {
   m = (uint64_t)((1ull << k) / (uint64_t)d) + 1;
 }
 
-int g_narrow_off = 0;
-unsigned long long* g_narrow_dbg = nullptr;  // test hook: 1 = never take this kernel (tdx_conv_gemm_force_small bit 256)
+int g_narrow_off = 0;                        // test hook: 1 = never take this kernel (tdx_conv_gemm_force_small bit 16, mask 0x10000)
+unsigned long long* g_narrow_dbg = nullptr;  // diagnostic builds (-DNARROW_STAMPS): per-phase cycle sums, see tdx_narrow_conv_stamps
 
 }  // namespace
 

@@ -24,6 +24,15 @@ void tdx_set_error(const char* fmt, ...);
   do {                           \
     if (!(cond)) TDX_FAIL(TDX_ERR_ARG, __VA_ARGS__); \
   } while (0)
+// Index of the current device into the library's per-device caches (kernel attributes set, CU counts, static scratch addresses): one
+// process may drive several GPUs, and each holds its own copy of every code object.
+constexpr int kTdxMaxDevices = 64;
+inline int tdx_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < kTdxMaxDevices ? dev : kTdxMaxDevices - 1;
+}
+
 #define TDX_CHECK_LAUNCH(name)                                                       \
   do {                                                                               \
     hipError_t e__ = hipGetLastError();                                              \

@@ -728,9 +728,15 @@ constexpr int kMaxDevices = 64;
 static __device__ __align__(256) float g_mse_scratch[kRedBlocks];
 static float* g_mse_scratch_ptr[kMaxDevices] = {};   // per device, filled on the first call made with that device current
 
-static int static_scratch(float** out) {
+static int static_scratch(float** out, hipStream_t st) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) TDX_FAIL(TDX_ERR_HIP, "tdx_mse_loss_grad_static: no current device (or index >= %d)", kMaxDevices);
+  // the array's address belongs to ONE device: a stream of another GPU would launch there with this GPU's address
+  if (st != nullptr) {
+    int sdev = -1;
+    if (hipStreamGetDevice(st, &sdev) == hipSuccess && sdev != dev)
+      TDX_FAIL(TDX_ERR_ARG, "tdx_mse_loss_grad_static: the stream belongs to device %d but device %d is current; make the stream's device current", sdev, dev);
+  }
   float* p = __atomic_load_n(&g_mse_scratch_ptr[dev], __ATOMIC_ACQUIRE);
   if (p == nullptr) {
     void* sym = nullptr;
@@ -748,9 +754,9 @@ extern "C" int tdx_mse_loss_grad_static(const float* pred, const float* target, 
   TDX_CHECK_ARG(n <= kStaticMaxN, "tdx_mse_loss_grad_static: n=%lld exceeds the static scratch's limit of %lld elements; use tdx_mse_loss_grad with a workspace",
                 (long long)n, (long long)kStaticMaxN);
   float* ws = nullptr;
-  const int rc = static_scratch(&ws);
-  if (rc != TDX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const int rc = static_scratch(&ws, st);
+  if (rc != TDX_OK) return rc;
   const int blocks = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
   // every partial the second kernel reads is written by the first one of THIS call: nothing has to start at zero
   hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, ws, (long)n, 2.0f / (float)n);

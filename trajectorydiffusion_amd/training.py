@@ -506,8 +506,6 @@ class TrainStep:
         F32, st, lib = _lib.TDX_F32, _lib.stream_ptr(), self.lib
         with torch.no_grad():
             self._refresh_packed_weights()
-            self._passes += 1
-            self.rng[0] = self._passes
             # layouts and embedding-row gathers, through the library like everything else (dtype / contiguity fixes are the only
             # torch ops left): (B, 2, L) -> zero-padded rows (B, L, 4); pos_enc[t] and the five embedding rows; num -> (B, 4)
             x_c, num_c = x_t.to(torch.float32).contiguous(), num.to(torch.float32).contiguous()
@@ -524,6 +522,8 @@ class TrainStep:
             if int(self._err.item()):                       # the step's only host synchronisation
                 self._err.zero_()
                 raise IndexError("TrainStep: time step or categorical attribute out of range")
+            self._passes += 1                               # (after the check: a rejected batch must not shift the dropout stream of later steps)
+            self.rng[0] = self._passes
             self.fw.run()
             _lib.check(lib.tdx_rows_to_chanfirst(self.out4.data_ptr(), 4, self.pred.data_ptr(), B, 2, L, F32, st), "rows -> eps_hat")
         return self.pred
@@ -656,6 +656,36 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         return None
+
+    # The Adam moments and the step count live in TrainStep (device buffers the fused kernel updates in place), not in
+    # torch.optim.Optimizer.state: checkpoint / resume through the standard optimizer face must carry them.
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["tdx_step_count"] = int(self.ts.step_count)
+        sd["tdx_moments"] = {n: (m.detach().clone(), v.detach().clone()) for n, (m, v) in self.ts.state.items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        step = sd.pop("tdx_step_count", None)
+        moments = sd.pop("tdx_moments", None)
+        if step is None or moments is None:
+            raise TdxError("FusedAdamW.load_state_dict: not a FusedAdamW state (no tdx_step_count / tdx_moments): the moments of a "
+                           "torch.optim.AdamW checkpoint are keyed by parameter index, not by name")
+        super().load_state_dict(sd)
+        unknown = [n for n in moments if n not in self.ts.params]
+        if unknown:
+            raise TdxError(f"FusedAdamW.load_state_dict: moments for unknown parameters {unknown[:3]}")
+        with torch.no_grad():
+            self.ts.state = {}
+            for n, (m, v) in moments.items():
+                p = self.ts.params[n]
+                if tuple(m.shape) != tuple(p.shape) or tuple(v.shape) != tuple(p.shape):
+                    raise TdxError(f"FusedAdamW.load_state_dict: moment shapes of {n} do not match the parameter")
+                self.ts.state[n] = (m.to(device=p.device, dtype=torch.float32).clone().contiguous(), v.to(device=p.device, dtype=torch.float32).clone().contiguous())
+        self.ts.step_count = int(step)
+        g = self.param_groups[0]
+        self.ts.set_lr(g["lr"])
 
 
 class _TrainForward(torch.autograd.Function):

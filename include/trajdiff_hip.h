@@ -342,6 +342,18 @@ int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, uint64_t se
  * step counts from 1.  Hyper-parameters are doubles, as torch keeps them: 1 - beta2 must be formed before rounding to fp32. */
 int tdx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int32_t step, void* stream);
+/* The same update for every tensor of one parameter group in ONE launch (torch.optim.AdamW(model.parameters(), ...), train.ipynb:131,208:
+ * ~200 tensors share one set of hyper-parameters, and one launch per tensor is launch-bound).  table_dev: a DEVICE-resident array of n
+ * descriptors; the element arithmetic is tdx_adamw_step's, so the result is bit-identical to n single-tensor calls. */
+typedef struct tdx_adamw_desc {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+} tdx_adamw_desc;
+int tdx_adamw_step_multi(const tdx_adamw_desc* table_dev, int32_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                         int32_t step, void* stream);
 
 /* ---- Latent path: SDUNet_CAR (Models/StableDiffusion.py:114-222) between
  * VAE_InvTrans.encode / decode (Models/VAE.py:135-192).  Every Conv1d / nn.Linear / attention projection of both models is a

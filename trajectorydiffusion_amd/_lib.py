@@ -88,6 +88,7 @@ _SIGNATURES = {
     "tdx_attention_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "tdx_dropout": (_i32, [_vp, _i32, _i32, _i32, _f32, _u64, C.c_uint32, _vp, _vp]),
     "tdx_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
+    "tdx_adamw_step_multi": (_i32, [_vp, _i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _vp]),
     "tdx_cross_attention": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_mha_small": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tdx_chanfirst_to_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

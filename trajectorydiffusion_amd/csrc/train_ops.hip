@@ -156,6 +156,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   m[i] = mi;
   v[i] = vi;
 }
+// every tensor of a parameter group in one launch: blockIdx.y = table entry, grid-stride over its elements (same arithmetic)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const tdx_adamw_desc* __restrict__ table, float omb1, float beta2, float omb2, float eps,
+                                                         float decay, float step_size, float bc2_sqrt) {
+  const tdx_adamw_desc d = table[blockIdx.y];
+  float* __restrict__ p = d.param;
+  const float* __restrict__ g = d.grad;
+  float* __restrict__ m = d.exp_avg;
+  float* __restrict__ v = d.exp_avg_sq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    float pi = p[i] * decay;
+    const float mi = m[i] + (gi - m[i]) * omb1;
+    const float vi = v[i] * beta2 + omb2 * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
 
 
 // ---- convolution weight gradient -----------------------------------------------------------------------------------------
@@ -374,6 +394,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int s = 0; s < splits; ++s) acc += part[(size_t)s * total + i];
   float* o = dw + ((size_t)co * cin_total + ci_off) * taps + k;
   *o = accumulate ? *o + acc : acc;
+}
+
+// The same sum for gradients whose rows are whole float4s, with the slabs spread over 16 classes per output: a level-0 gradient
+// (128 x 384 values) is cut into 512 slabs, and one thread per output walking them one after the other is 192 workgroups each
+// waiting for 512 dependent-latency loads (0.13 ms for 100 MB).  Block = 16 float4 columns x 16 classes; class q adds slabs
+// q, q + 16, ... in order, then the classes are added in order: a fixed association for a given slab count, no atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __restrict__ part, int splits, int cout, int kdim4,
+                                                             float* __restrict__ dw, int ld4, int off4, int accumulate) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ f32x4 red[16][16];
+  const long total4 = (long)cout * kdim4;
+  const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + c;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (i < total4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+    int s = q;
+    for (; s + 48 < splits; s += 64) {   // four independent loads in flight per thread
+      const f32x4 v0 = src[(size_t)s * total4], v1 = src[(size_t)(s + 16) * total4], v2 = src[(size_t)(s + 32) * total4], v3 = src[(size_t)(s + 48) * total4];
+      acc = acc + v0;
+      acc = acc + v1;
+      acc = acc + v2;
+      acc = acc + v3;
+    }
+    for (; s < splits; s += 16) acc = acc + src[(size_t)s * total4];
+  }
+  red[q][c] = acc;
+  __syncthreads();
+  if (q == 0 && i < total4) {
+    f32x4 t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = t + red[k][c];
+    const long co = i / kdim4, k4 = i - co * kdim4;
+    f32x4* o = reinterpret_cast<f32x4*>(dw) + co * ld4 + off4 + k4;
+    *o = accumulate ? *o + t : t;
+  }
+#endif
 }
 
 // ---- GroupNorm (+ Swish) backward ------------------------------------------------------------------------------------------
@@ -808,6 +865,17 @@ extern "C" int tdx_adamw_step(float* param, const float* grad, float* exp_avg, f
   return TDX_OK;
 }
 
+static int wgrad_cus() {   // CUs of the current device (per device: a process may drive several)
+  static int n_dev[kTdxMaxDevices] = {};
+  int& n = n_dev[tdx_device_slot()];
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
                               float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
                               void* stream) {
@@ -830,12 +898,22 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   const bool big = !(g_wgrad_force & 1) && dtype == TDX_F32 && (!s2 || (s.taps == 3 && s.lvirt == s.lin)) && cout % 128 == 0 && s.cin % 128 == 0 && dy_ld % 4 == 0 &&
                    dy_off % 4 == 0 && s.src_ld % 4 == 0 && s.ch_off % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)s.src & 15) == 0;
   int splits;
-  if (big) {  // one 512-thread workgroup per CU: aim at two full rounds of the 256 CUs
-    const int tiles = (cout / 128) * (s.cin / 128);
-    splits = std::max(1, 512 / tiles);
-    splits = std::min(splits, (N + 31) / 32);
+  if (big) {
+    // one 512-thread workgroup per CU at a time, all of equal work: the fewest slabs whose workgroup count fills whole rounds of the
+    // CUs (every slab costs one gradient-sized partial written and read back: 100 MB for 512 slabs of a 128 x 384 gradient)
+    const int tiles = (cout / 128) * (s.cin / 128), cus = wgrad_cus();
+    const int smax = std::max(1, std::min(512, (N + 255) / 256));
+    double best = 0.0;
+    for (int k = 1; k <= smax; ++k) best = std::max(best, (double)(tiles * k) / (double)(((tiles * k + cus - 1) / cus) * cus));
+    splits = 1;
+    while (splits < smax && (double)(tiles * splits) / (double)(((tiles * splits + cus - 1) / cus) * cus) < 0.97 * best) ++splits;
+    if (g_wgrad_force & 4) splits = std::min(std::max(1, 512 / tiles), (N + 31) / 32);   // (the former rule: two rounds' worth)
   } else {
-    splits = std::min(64, (N + 2047) / 2048);
+    // few tiles (the stem's 4 -> 128 and the head's 128 -> 4 channels): the rows are all the parallelism there is, so cut them finer
+    // (about 2048 workgroups; 64 slabs left 384 workgroups of a latency-bound loop on 256 CUs: 0.35 ms for 105 MB of dY)
+    const int tiles = ((cout + 63) / 64) * ((s.cin + 63) / 64) * s.taps;
+    splits = std::max(std::min(64, (N + 2047) / 2048), std::min(512, 2048 / tiles));
+    splits = std::max(1, std::min(splits, (N + 255) / 256));
   }
   if ((int64_t)splits * per_split > ws_floats) splits = (int)(ws_floats / per_split);
   TDX_CHECK_ARG(splits >= 1, "tdx_conv_wgrad: workspace of %lld floats is smaller than one gradient (%lld)", (long long)ws_floats, (long long)per_split);
@@ -852,8 +930,13 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
     if (dtype == TDX_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, st, ws, splits, cout, s.cin, s.taps, dw,
-                     cin_total, ci_off, accumulate);
+  const int kdim = s.cin * s.taps;
+  if (!(g_wgrad_force & 2) && kdim % 4 == 0 && (cin_total * s.taps) % 4 == 0 && (ci_off * s.taps) % 4 == 0 && ((uintptr_t)dw & 15) == 0 && ((uintptr_t)ws & 15) == 0)
+    hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)((per_split / 4 + 15) / 16)), dim3(256), 0, st, ws, splits, cout, kdim / 4, dw,
+                       cin_total * s.taps / 4, ci_off * s.taps / 4, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, st, ws, splits, cout, s.cin, s.taps, dw,
+                       cin_total, ci_off, accumulate);
   TDX_CHECK_LAUNCH("conv_wgrad");
   return TDX_OK;
 }
@@ -983,6 +1066,18 @@ extern "C" int tdx_dropout(float* x, int32_t ld, int32_t n, int32_t c, float p, 
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, n, c, thresh,
                      1.0f / (1.0f - p), seed, layer, step_ctr);
   TDX_CHECK_LAUNCH("dropout_kernel");
+  return TDX_OK;
+}
+
+extern "C" int tdx_adamw_step_multi(const tdx_adamw_desc* table_dev, int32_t n, double lr, double beta1, double beta2, double eps,
+                                    double weight_decay, int32_t step, void* stream) {
+  TDX_CHECK_ARG(table_dev && n > 0 && n <= 65535, "tdx_adamw_step_multi: bad table (n=%d)", n);
+  TDX_CHECK_ARG(step >= 1, "tdx_adamw_step_multi: step=%d (1-based)", step);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float decay = (float)(1.0 - lr * weight_decay), step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(128, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, decay, step_size, bc2_sqrt);
+  TDX_CHECK_LAUNCH("adamw_multi_kernel");
   return TDX_OK;
 }
 

@@ -16,6 +16,8 @@ Not covered: bf16 training (the reference trains in fp32).
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -63,6 +65,10 @@ class TrainStep:
         self.fw.release = lambda t: None            # saved activations: nothing is reused
         self.bw = engine.Program(device, torch.float32)
         self.bw.release = lambda t: None
+        # the embedding-side GEMMs have B rows only (8 row tiles at B = 1024) and K up to 1280: with room for split-K slices they run as
+        # ~64 workgroups instead of 8-16 (tdx_conv_desc.ws).  One buffer for both programs: they never run concurrently.
+        if os.environ.get("TDX_TRAIN_SPLITK", "1") != "0":
+            self.fw.split_k_ws = self.bw.split_k_ws = torch.empty(8 << 20, dtype=torch.float32, device=device)
         self._back: List[Callable[[], None]] = []
         self._repack: List[Callable[[], None]] = []        # torch plumbing refreshed every step: padded stand-ins, bias sums
         self._repack_torch: List[Callable[[], None]] = []  # the weight layouts as torch statements (tests check tdx_pack_weights against them)
@@ -75,6 +81,7 @@ class TrainStep:
         # no residual operand (one tensor read less, and the persistent conv kernel takes the launch)
         self._gwritten: Dict[int, List[Tuple[int, int]]] = {}
         self._gzero: List[torch.Tensor] = []        # gradient buffers that still need the per-step zero fill
+        self._adamw_key, self._adamw_tab = None, None   # device table of the optimizer's tensors (tdx_adamw_step_multi)
         self._keep: List[torch.Tensor] = []
         self.params = dict(model.named_parameters())
         for n, p in self.params.items():
@@ -622,15 +629,23 @@ class TrainStep:
     def optimizer_step(self) -> None:
         """torch.optim.AdamW(lr, betas, eps, weight_decay) over every parameter that received a gradient (train.ipynb:131,208)."""
         self.step_count += 1
-        st = _lib.stream_ptr()
+        rows = []
         for n, g in self.named_gradients().items():
             p = self.params[n]
             if n not in self.state:
                 self.state[n] = (torch.zeros_like(p), torch.zeros_like(p))
             mm, vv = self.state[n]
-            _lib.check(self.lib.tdx_adamw_step(p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), self.lr, self.betas[0],
-                                               self.betas[1], self.eps, self.wd, self.step_count, st), "tdx_adamw_step")
-            torch.autograd.graph.increment_version(p)   # the inference side re-packs its weights when a parameter's version moves
+            rows.append((p.data.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel()))
+        # one launch over a device-resident table of (param, grad, exp_avg, exp_avg_sq, n) rows (tdx_adamw_desc); the table is rebuilt
+        # when any of those buffers has moved (a parameter re-assigned, moments restored from a checkpoint)
+        key = tuple(rows)
+        if self._adamw_key != key:
+            self._adamw_tab = torch.tensor(rows, dtype=torch.int64).to(self.dev)
+            self._adamw_key = key
+        _lib.check(self.lib.tdx_adamw_step_multi(self._adamw_tab.data_ptr(), len(rows), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                                 self.step_count, _lib.stream_ptr()), "tdx_adamw_step_multi")
+        for n in self.named_gradients():
+            torch.autograd.graph.increment_version(self.params[n])   # the inference side re-packs its weights when a parameter's version moves
 
 
 class FusedAdamW(torch.optim.Optimizer):

@@ -666,80 +666,204 @@ __global__ __launch_bounds__(256) void traj_rowsum_kernel(const float* __restric
   float* o = out + (size_t)b * out_ld + k;
   *o = accumulate ? *o + acc : acc;
 }
+// the same sums, four columns per thread and eight row loads in flight; rows are added in the same order (bit-identical)
+__global__ __launch_bounds__(256) void traj_rowsum_v4_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int out_ld, int B, int L,
+                                                            int c4, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * c4) return;
+  const int b = (int)(i / c4), k = (int)(i - (long)b * c4) * 4;
+  const float* src = x + (size_t)b * L * ld + k;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int l = 0;
+  for (; l + 8 <= L; l += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(l + u) * ld);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = acc + v[u];
+  }
+  for (; l < L; ++l) acc = acc + *reinterpret_cast<const f32x4*>(src + (size_t)l * ld);
+  f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)b * out_ld + k);
+  *o = accumulate ? *o + acc : acc;
+}
 
 // nn.Embedding backward: dtable[r][c] (+)= sum over samples b and index columns j with idx[b * idx_ld + j] == r of
-// dvec[b * dvec_ld + j * dim + c].  One thread per table element scanning the batch: fixed order, no atomics.
+// dvec[b * dvec_ld + j * dim + c], in (b, j) order: fixed association, no atomics.  One workgroup per table row r.  Finding the matches
+// is the parallel part: 4096 (b, j) pairs at a time, one pair per thread and load (16 loads in flight), a ballot per wave, the 64 masks
+// through LDS; then every thread walks the set bits in pair order and adds its columns of the matching rows.  (One thread per table
+// element scanning the batch by itself: 4096 dependent-latency iterations, 0.44 ms for the 256 x 128 cell table at B = 1024.)
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ idx, int idx_ld, int ncols, const float* __restrict__ dvec,
                                                            int dvec_ld, float* __restrict__ dtable, int rows, int dim, int B, int accumulate) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)rows * dim) return;
-  const int r = (int)(i / dim), c = (int)(i - (long)r * dim);
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int j = 0; j < ncols; ++j)
-      if (idx[(size_t)b * idx_ld + j] == r) acc += dvec[(size_t)b * dvec_ld + j * dim + c];
-  dtable[i] = accumulate ? dtable[i] + acc : acc;
+  __shared__ unsigned long long masks[16][4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long npairs = (long)B * ncols;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // columns tid + 256 k (dim <= 1024)
+  for (long p0 = 0; p0 < npairs; p0 += 4096) {
+    bool hit[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const long pr = p0 + k * 256 + tid;
+      hit[k] = false;
+      if (pr < npairs) {
+        const long b = pr / ncols;
+        hit[k] = idx[(size_t)b * idx_ld + (int)(pr - b * ncols)] == r;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const unsigned long long m = __ballot(hit[k]);
+      if (lane == 0) masks[k][wave] = m;
+    }
+    __syncthreads();
+    for (int m = 0; m < 64; ++m) {
+      const unsigned long long mv = masks[m >> 2][m & 3];
+      unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
+      while (mask) {
+        const int bit = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const long pr = p0 + (long)m * 64 + bit;
+        const long b = pr / ncols;
+        const float* v = dvec + (size_t)b * dvec_ld + (size_t)(pr - b * ncols) * dim;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = tid + 256 * k;
+          if (c < dim) acc[k] += v[c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + 256 * k;
+    if (c < dim) {
+      float* o = dtable + (size_t)r * dim + c;
+      *o = accumulate ? *o + acc[k] : acc[k];
+    }
+  }
 }
 
 // Mid-block attention backward (TrajUNetBlocks.py:117-125), fp32, L <= 16 tokens: one workgroup per trajectory.
 //   S = Q K^T * scale, P = softmax(S), O = P V;  dV = P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dP * P)),
 //   dQ = dS K * scale, dK = dS^T Q * scale.   qkv / dqkv rows are (q | k | v) of 3 * C channels.
+// Phase 1 (S and dP, two C-long dot products per token pair): a wave owns two query rows at a time and its lanes split the channels, so
+// every load instruction reads 1 KB of one contiguous row and a K / V row is fetched once per row pair (one thread per (i, j) pair read
+// 16 different rows per instruction and every row 16 times: 4 MB through the L1 per trajectory, 0.52 ms per step).  Phase 2: a thread
+// owns a channel column, loads its dO / K / Q values of all tokens once and forms the column's dQ, dK, dV from P and dS in LDS.
+template <bool VEC>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
                                                            int L, int C, float scale) {
-  __shared__ float P[16 * 16], dS[16 * 16];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float Sraw[16 * 16], dPraw[16 * 16], P[16 * 16], dS[16 * 16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = qkv + (size_t)b * L * 3 * C;
   const float* dob = dout + (size_t)b * L * C;
   float* dbase = dqkv + (size_t)b * L * 3 * C;
-  const int i = tid >> 4, j = tid & 15;  // thread (i, j) owns score S[i][j] and dP[i][j]
-  float s = 0.f, dp = 0.f;
-  if (i < L && j < L) {
-    const float* q = base + (size_t)i * 3 * C;
-    const float* k = base + (size_t)j * 3 * C + C;
-    const float* v = base + (size_t)j * 3 * C + 2 * C;
-    const float* go = dob + (size_t)i * C;
-    if ((C & 3) == 0 && ((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0)) {  // 16-byte loads, same summation order
-      for (int c = 0; c < C; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(q + c), bk = *reinterpret_cast<const f32x4*>(k + c);
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(go + c), v4 = *reinterpret_cast<const f32x4*>(v + c);
+  constexpr int W = VEC ? 4 : 1;
+  for (int i0 = 2 * wave; i0 < L; i0 += 8) {
+    const int i1 = i0 + 1 < L ? i0 + 1 : i0;   // (an odd last row is computed twice and written once)
+    float s[2][16], dp[2][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[0][j] = s[1][j] = dp[0][j] = dp[1][j] = 0.f;
+    for (int c = lane * W; c < C; c += 64 * W) {
+      float q0[W], q1[W], g0[W], g1[W];
+      if constexpr (VEC) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)i0 * 3 * C + c), a1 = *reinterpret_cast<const f32x4*>(base + (size_t)i1 * 3 * C + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dob + (size_t)i0 * C + c), g1v = *reinterpret_cast<const f32x4*>(dob + (size_t)i1 * C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s = fmaf(a[e], bk[e], s);
-          dp = fmaf(g4[e], v4[e], dp);
+          q0[e] = a[e];
+          q1[e] = a1[e];
+          g0[e] = g[e];
+          g1[e] = g1v[e];
+        }
+      } else {
+        q0[0] = base[(size_t)i0 * 3 * C + c];
+        q1[0] = base[(size_t)i1 * 3 * C + c];
+        g0[0] = dob[(size_t)i0 * C + c];
+        g1[0] = dob[(size_t)i1 * C + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < L) {
+          float kk[W], vv[W];
+          if constexpr (VEC) {
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(base + (size_t)j * 3 * C + C + c), v4 = *reinterpret_cast<const f32x4*>(base + (size_t)j * 3 * C + 2 * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              kk[e] = k4[e];
+              vv[e] = v4[e];
+            }
+          } else {
+            kk[0] = base[(size_t)j * 3 * C + C + c];
+            vv[0] = base[(size_t)j * 3 * C + 2 * C + c];
+          }
+#pragma unroll
+          for (int e = 0; e < W; ++e) {
+            s[0][j] = fmaf(q0[e], kk[e], s[0][j]);
+            s[1][j] = fmaf(q1[e], kk[e], s[1][j]);
+            dp[0][j] = fmaf(g0[e], vv[e], dp[0][j]);
+            dp[1][j] = fmaf(g1[e], vv[e], dp[1][j]);
+          }
         }
       }
-    } else {
-      for (int c = 0; c < C; ++c) {
-        s = fmaf(q[c], k[c], s);
-        dp = fmaf(go[c], v[c], dp);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < L) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float a = s[r][j], d = dp[r][j];
+          for (int o = 32; o >= 1; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            d += __shfl_xor(d, o, 64);
+          }
+          if (lane == 0 && (r == 0 || i1 != i0)) {
+            Sraw[(r ? i1 : i0) * 16 + j] = a * scale;
+            dPraw[(r ? i1 : i0) * 16 + j] = d;
+          }
+        }
       }
     }
-    s *= scale;
   }
+  __syncthreads();
+  const int i = tid >> 4, j = tid & 15;  // thread (i, j) owns score S[i][j] and dP[i][j]
+  const bool in = i < L && j < L;
+  const float sc = in ? Sraw[tid] : 0.f, dpv = in ? dPraw[tid] : 0.f;
   // softmax over j (16 consecutive lanes), masked to j < L
-  float m = (i < L && j < L) ? s : -INFINITY;
+  float m = in ? sc : -INFINITY;
   for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  float e = (i < L && j < L) ? expf(s - m) : 0.f;
+  const float e = in ? expf(sc - m) : 0.f;
   float sum = e;
   for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-  const float p = (i < L && j < L) ? e / sum : 0.f;
-  float t = dp * p;
+  const float p = in ? e / sum : 0.f;
+  float t = dpv * p;
   for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
   P[tid] = p;
-  dS[tid] = p * (dp - t) * scale;   // already multiplied by the score scale
+  dS[tid] = p * (dpv - t) * scale;   // already multiplied by the score scale
   __syncthreads();
   // dV[j][c] = sum_i P[i][j] dO[i][c];  dQ[i][c] = sum_j dS[i][j] K[j][c];  dK[j][c] = sum_i dS[i][j] Q[i][c]
-  for (int idx = tid; idx < L * C; idx += 256) {
-    const int r = idx / C, c = idx - r * C;
-    float dv = 0.f, dq = 0.f, dk = 0.f;
-    for (int o = 0; o < L; ++o) {
-      dv = fmaf(P[o * 16 + r], dob[(size_t)o * C + c], dv);
-      dq = fmaf(dS[r * 16 + o], base[(size_t)o * 3 * C + C + c], dq);
-      dk = fmaf(dS[o * 16 + r], base[(size_t)o * 3 * C + c], dk);
+  for (int c = tid; c < C; c += 256) {
+    float go[16], kc[16], qc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const bool ok = o < L;
+      go[o] = ok ? dob[(size_t)o * C + c] : 0.f;
+      kc[o] = ok ? base[(size_t)o * 3 * C + C + c] : 0.f;
+      qc[o] = ok ? base[(size_t)o * 3 * C + c] : 0.f;
     }
-    dbase[(size_t)r * 3 * C + c] = dq;
-    dbase[(size_t)r * 3 * C + C + c] = dk;
-    dbase[(size_t)r * 3 * C + 2 * C + c] = dv;
+    for (int r = 0; r < L; ++r) {
+      float dv = 0.f, dq = 0.f, dk = 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {   // (rows o >= L of P / dS are zero, and so are the padded column values)
+        dv = fmaf(P[o * 16 + r], go[o], dv);
+        dq = fmaf(dS[r * 16 + o], kc[o], dq);
+        dk = fmaf(dS[o * 16 + r], qc[o], dk);
+      }
+      dbase[(size_t)r * 3 * C + c] = dq;
+      dbase[(size_t)r * 3 * C + C + c] = dk;
+      dbase[(size_t)r * 3 * C + 2 * C + c] = dv;
+    }
   }
 }
 
@@ -1033,8 +1157,12 @@ extern "C" int tdx_act_bwd(const float* dy, int32_t dy_ld, const float* ref, int
 extern "C" int tdx_traj_rowsum(const float* x, int32_t ld, float* out, int32_t out_ld, int32_t B, int32_t L, int32_t c, int32_t accumulate,
                                void* stream) {
   TDX_CHECK_ARG(x && out && B > 0 && L > 0 && c > 0 && ld >= c && out_ld >= c, "tdx_traj_rowsum: bad arguments");
-  hipLaunchKernelGGL(traj_rowsum_kernel, dim3((unsigned)(((long)B * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, out, out_ld, B, L, c,
-                     accumulate);
+  if (c % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(traj_rowsum_v4_kernel, dim3((unsigned)(((long)B * (c / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, out, out_ld,
+                       B, L, c / 4, accumulate);
+  else
+    hipLaunchKernelGGL(traj_rowsum_kernel, dim3((unsigned)(((long)B * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, out, out_ld, B, L, c,
+                       accumulate);
   TDX_CHECK_LAUNCH("traj_rowsum_kernel");
   return TDX_OK;
 }
@@ -1043,7 +1171,8 @@ extern "C" int tdx_embedding_bwd(const int64_t* idx, int32_t idx_ld, int32_t nco
                                  int32_t dim, int32_t B, int32_t accumulate, void* stream) {
   TDX_CHECK_ARG(idx && dvec && dtable && ncols > 0 && rows > 0 && dim > 0 && B > 0 && idx_ld >= ncols && dvec_ld >= ncols * dim,
                 "tdx_embedding_bwd: bad arguments");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(((long)rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, idx_ld, ncols,
+  TDX_CHECK_ARG(dim <= 1024, "tdx_embedding_bwd: dim=%d exceeds 1024 columns per table row", dim);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, idx, idx_ld, ncols,
                      dvec, dvec_ld, dtable, rows, dim, B, accumulate);
   TDX_CHECK_LAUNCH("embedding_bwd_kernel");
   return TDX_OK;
@@ -1052,7 +1181,11 @@ extern "C" int tdx_embedding_bwd(const int64_t* idx, int32_t idx_ld, int32_t nco
 extern "C" int tdx_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t B, int32_t L, int32_t C, void* stream) {
   TDX_CHECK_ARG(qkv && dout && dqkv && B > 0 && L > 0 && C > 0, "tdx_attention_bwd: bad arguments");
   if (L > 16) TDX_FAIL(TDX_ERR_UNSUPPORTED, "tdx_attention_bwd: %d tokens > 16 supported", L);
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, qkv, dout, dqkv, L, C, 1.0f / sqrtf((float)C));
+  const float scale = 1.0f / sqrtf((float)C);
+  if ((C & 3) == 0 && ((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0))
+    hipLaunchKernelGGL(attention_bwd_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, qkv, dout, dqkv, L, C, scale);
+  else
+    hipLaunchKernelGGL(attention_bwd_kernel<false>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, qkv, dout, dqkv, L, C, scale);
   TDX_CHECK_LAUNCH("attention_bwd_kernel");
   return TDX_OK;
 }

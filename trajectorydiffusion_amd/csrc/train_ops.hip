@@ -9,7 +9,8 @@
 namespace {
 
 constexpr int kRedBlocks = 1024;
-int g_wgrad_force = 0;  // tests: bit 0 = never take the large-tile weight-gradient kernel  // first-stage partials of the scalar / column reductions
+int g_wgrad_force = 0;  // tests (tdx_conv_wgrad_debug): 1 = never take the large-tile weight-gradient kernel, 2 = one-thread-per-output slab sum,
+                        // 4 = the former slab count (two rounds' worth), 8 = GroupNorm backward re-reads its rows in every sweep  // first-stage partials of the scalar / column reductions
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {  // fixed-order tree: lanes, then the four waves
   v = wave_sum(v);
@@ -440,43 +441,106 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __res
 // One wave per (trajectory, channel window), same decomposition as the forward kernel; four sweeps over the rows (statistics
 // are recomputed, nothing but x was saved by the forward pass).  Per-channel sums are written per trajectory
 // (dgamma_rows / dbeta_rows, (B, C) fp32); tdx_colsum over those rows gives dgamma / dbeta in a fixed order.
-template <typename T>
+// NIT > 0: the wave's rows of x and dy (NIT row iterations per lane) are loaded ONCE, all at the start, and the four sweeps run on
+// registers; a sweep that re-reads its rows pays one dependent memory round trip per row iteration, 100 of them at L = 200, and
+// that latency, not the 315 MB of traffic, was the kernel's time (0.13 ms per full-resolution layer).  NIT == 0: the re-reading
+// form, for trajectories too long for the register file.  Same arithmetic and summation order in both.
+template <typename T, int NIT, int S>
 __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
                                                                int dy_off, T* __restrict__ dx, int dx_ld, int dx_off,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ dgamma_rows, float* __restrict__ dbeta_rows, int B,
-                                                               int L, int C, int cpg, int lpr, float eps, int act, int accumulate) {
+                                                               int L, int C, int cpg, int lpr, float eps, int act, int accumulate,
+                                                               int rows_per_part) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = VEC / 2;
-  const int lane = threadIdx.x & 63;
+  constexpr int NR = NIT > 0 ? NIT : 1;
+  constexpr bool KEEP = NIT > 0 && sizeof(T) == 4;   // fp32 rows in registers: exact to overwrite dy with dxh
+  static_assert(S == 1 || NIT > 0, "split sweeps keep their rows in registers");
+  __shared__ float red[S > 1 ? 3 : 1][4][64][4];       // [exchange][wave][column][sums]
+  __shared__ float redp[S > 1 ? 4 : 1][64][2 * VEC];   // per-channel dgamma | dbeta partials of the S waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int W = lpr * VEC;
   const int wins = C / W;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long)B * wins) return;  // wave-uniform
-  const int b = (int)(wid / wins), win = (int)(wid % wins);
+  const long wid = ((long)blockIdx.x * 4 + wave) / S;   // (trajectory, window) item; S consecutive waves share one
+  const int part = wave % S;
+  const bool active = wid < (long)B * wins;             // wave-uniform, the same for the S waves of an item
+  if (S == 1 && !active) return;                        // (split sweeps: idle waves still take part in the barriers)
+  const int b = active ? (int)(wid / wins) : 0, win = active ? (int)(wid % wins) : 0;
   const int col = lane % lpr, rl = lane / lpr, rpi = 64 / lpr;
   const int ch = win * W + col * VEC;
   const T* xb = x + ((size_t)b * L) * x_ld + ch;
   const T* dyb = dy + ((size_t)b * L) * dy_ld + dy_off + ch;
   T* dxb = dx + ((size_t)b * L) * dx_ld + dx_off + ch;
   const bool split = cpg < VEC;
-  auto group_sum = [&](float& lo, float& hi) {
+  // this wave's rows: [l0, L1)
+  const int l0 = S > 1 ? part * rows_per_part : 0;
+  const int L1 = !active ? 0 : (S > 1 ? (l0 + rows_per_part < L ? l0 + rows_per_part : L) : L);
+  int pass = 0;
+  // sums over the wave's rows -> over the item's rows (the other waves' partials through LDS, added in the order of the parts) -> over the group
+  auto group_sum2 = [&](float& lo, float& hi, float& lo2, float& hi2) {
     for (int o = 32; o >= lpr; o >>= 1) {
       lo += __shfl_xor(lo, o, 64);
       hi += __shfl_xor(hi, o, 64);
+      lo2 += __shfl_xor(lo2, o, 64);
+      hi2 += __shfl_xor(hi2, o, 64);
+    }
+    if constexpr (S > 1) {
+      if (rl == 0) *reinterpret_cast<f32x4*>(&red[pass][wave][col][0]) = (f32x4){lo, hi, lo2, hi2};
+      __syncthreads();
+      const int w0 = wave - part;
+      lo = hi = lo2 = hi2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&red[pass][w0 + k][col][0]);
+        lo += v[0];
+        hi += v[1];
+        lo2 += v[2];
+        hi2 += v[3];
+      }
+      ++pass;
     }
     if (!split) {
       lo += hi;
-      for (int o = 1; o * VEC < cpg; o <<= 1) lo += __shfl_xor(lo, o, 64);
+      lo2 += hi2;
+      for (int o = 1; o * VEC < cpg; o <<= 1) {
+        lo += __shfl_xor(lo, o, 64);
+        lo2 += __shfl_xor(lo2, o, 64);
+      }
       hi = lo;
+      hi2 = lo2;
     }
   };
-  auto rowv = [&](const T* base, int ld, int l, float (&v)[VEC]) { Elem<T>::unpack(*reinterpret_cast<const u32x4*>(base + (size_t)l * ld), v); };
+  auto group_sum = [&](float& lo, float& hi) {
+    float z0 = 0.f, z1 = 0.f;
+    group_sum2(lo, hi, z0, z1);
+  };
+  u32x4 hx[NR], hg[NR];
+  if constexpr (NIT > 0) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int l = l0 + rl + i * rpi;
+      hx[i] = l < L1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld) : (u32x4){0u, 0u, 0u, 0u};
+      hg[i] = l < L1 ? *reinterpret_cast<const u32x4*>(dyb + (size_t)l * dy_ld) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  auto xrow = [&](int i, int l, float (&v)[VEC]) {
+    if constexpr (NIT > 0) Elem<T>::unpack(hx[i], v);
+    else Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
+  };
+  auto grow = [&](int i, int l, float (&v)[VEC]) {
+    if constexpr (NIT > 0) Elem<T>::unpack(hg[i], v);
+    else Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dyb + (size_t)l * dy_ld), v);
+  };
+  const int nit = NIT > 0 ? NIT : (L - rl + rpi - 1) / rpi;   // (NIT == 0 only with S == 1: l0 = 0, L1 = L)
   const float inv_cnt = 1.0f / ((float)cpg * (float)L);
   float s_lo = 0.f, s_hi = 0.f;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = l0 + rl + i * rpi;
+    if (l >= L1) break;
     float v[VEC];
-    rowv(xb, x_ld, l, v);
+    xrow(i, l, v);
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       s_lo += v[j];
@@ -486,9 +550,12 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
   group_sum(s_lo, s_hi);
   const float m_lo = s_lo * inv_cnt, m_hi = s_hi * inv_cnt;
   float q_lo = 0.f, q_hi = 0.f;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = l0 + rl + i * rpi;
+    if (l >= L1) break;
     float v[VEC];
-    rowv(xb, x_ld, l, v);
+    xrow(i, l, v);
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       const float a = v[j] - m_lo, c = v[H + j] - m_hi;
@@ -518,10 +585,13 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
   float dg[VEC], db[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) dg[j] = db[j] = 0.f;
-  for (int l = rl; l < L; l += rpi) {
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = l0 + rl + i * rpi;
+    if (l >= L1) break;
     float v[VEC], g[VEC];
-    rowv(xb, x_ld, l, v);
-    rowv(dyb, dy_ld, l, g);
+    xrow(i, l, v);
+    grow(i, l, g);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float xh = (v[j] - (j < H ? m_lo : m_hi)) * (j < H ? r_lo : r_hi);
@@ -536,10 +606,11 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
         a_hi += dxh;
         c_hi += dxh * xh;
       }
+      g[j] = dxh;
     }
+    if constexpr (KEEP) hg[i] = Elem<T>::pack(g);   // dy's registers now hold dxh: the last sweep does not evaluate the activation again
   }
-  group_sum(a_lo, a_hi);
-  group_sum(c_lo, c_hi);
+  group_sum2(a_lo, a_hi, c_lo, c_hi);
   const float ma_lo = a_lo * inv_cnt, ma_hi = a_hi * inv_cnt, mc_lo = c_lo * inv_cnt, mc_hi = c_hi * inv_cnt;
 #pragma unroll
   for (int j = 0; j < VEC; ++j)
@@ -547,28 +618,101 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
       dg[j] += __shfl_xor(dg[j], o, 64);
       db[j] += __shfl_xor(db[j], o, 64);
     }
-  if (rl == 0) {
+  if constexpr (S > 1) {   // the S waves' per-channel sums, added in the order of the parts by the first of them
+    if (rl == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        redp[wave][col][j] = dg[j];
+        redp[wave][col][VEC + j] = db[j];
+      }
+    }
+    __syncthreads();
+    if (rl == 0 && part == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        dg[j] = db[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          dg[j] += redp[wave + k][col][j];
+          db[j] += redp[wave + k][col][VEC + j];
+        }
+      }
+    }
+  }
+  if (rl == 0 && part == 0 && active) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       dgamma_rows[(size_t)b * C + ch + j] = dg[j];
       dbeta_rows[(size_t)b * C + ch + j] = db[j];
     }
   }
-  for (int l = rl; l < L; l += rpi) {
-    float v[VEC], g[VEC], o[VEC];
-    rowv(xb, x_ld, l, v);
-    rowv(dyb, dy_ld, l, g);
-    if (accumulate) rowv(dxb, dx_ld, l, o);
+  auto dx_of = [&](int i, int l, float (&o)[VEC]) {
+    float v[VEC], g[VEC];
+    xrow(i, l, v);
+    grow(i, l, g);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float r = j < H ? r_lo : r_hi;
       const float xh = (v[j] - (j < H ? m_lo : m_hi)) * r;
-      const float dxh = du_of(xh, g[j], j) * gm[j];
-      const float d = r * (dxh - (j < H ? ma_lo : ma_hi) - xh * (j < H ? mc_lo : mc_hi));
-      o[j] = accumulate ? o[j] + d : d;
+      const float dxh = KEEP ? g[j] : du_of(xh, g[j], j) * gm[j];
+      o[j] = r * (dxh - (j < H ? ma_lo : ma_hi) - xh * (j < H ? mc_lo : mc_hi));
     }
+  };
+  if constexpr (NIT > 0 && sizeof(T) == 4) {
+    if (accumulate) {
+      // the gradients take dy's registers, then the rows of dx already there are fetched together into x's (no load waits for a store)
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        float o[VEC];
+        dx_of(i, l0 + rl + i * rpi, o);
+        hg[i] = Elem<T>::pack(o);
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int l = l0 + rl + i * rpi;
+        if (l < L1) hx[i] = *reinterpret_cast<const u32x4*>(dxb + (size_t)l * dx_ld);
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int l = l0 + rl + i * rpi;
+        if (l >= L1) break;
+        float o[VEC], d[VEC];
+        Elem<T>::unpack(hx[i], o);
+        Elem<T>::unpack(hg[i], d);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = o[j] + d[j];
+        *reinterpret_cast<u32x4*>(dxb + (size_t)l * dx_ld) = Elem<T>::pack(o);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < nit; ++i) {
+    const int l = l0 + rl + i * rpi;
+    if (l >= L1) break;
+    float o[VEC], d[VEC];
+    if (accumulate) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dxb + (size_t)l * dx_ld), o);
+    dx_of(i, l, d);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = accumulate ? o[j] + d[j] : d[j];
     *reinterpret_cast<u32x4*>(dxb + (size_t)l * dx_ld) = Elem<T>::pack(o);
   }
+}
+
+template <typename T>
+void launch_gn_bwd(int nit, int parts, int rows_per_part, dim3 grid, hipStream_t st, const void* x, int x_ld, const void* dy, int dy_ld, int dy_off,
+                   void* dx, int dx_ld, int dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int B, int L, int C,
+                   int cpg, int lpr, float eps, int act, int accumulate) {
+#define TDX_GNB(N, S)                                                                                                                            \
+  hipLaunchKernelGGL((groupnorm_act_bwd_kernel<T, N, S>), grid, dim3(256), 0, st, (const T*)x, x_ld, (const T*)dy, dy_ld, dy_off, (T*)dx, dx_ld, \
+                     dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate, rows_per_part)
+  if (parts == 4) TDX_GNB(8, 4);
+  else if (parts == 2) TDX_GNB(8, 2);
+  else if (nit <= 2) TDX_GNB(2, 1);
+  else if (nit <= 4) TDX_GNB(4, 1);
+  else if (nit <= 8) TDX_GNB(8, 1);
+  else TDX_GNB(0, 1);
+#undef TDX_GNB
 }
 
 // ---- row re-indexing of data gradients -----------------------------------------------------------------------------------
@@ -1084,15 +1228,23 @@ extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy
   TDX_CHECK_ARG(x_ld % vec == 0 && dy_ld % vec == 0 && dy_off % vec == 0 && dx_ld % vec == 0 && dx_off % vec == 0 && x_ld >= C &&
                     dy_off + C <= dy_ld && dx_off + C <= dx_ld,
                 "tdx_groupnorm_act_bwd: leading dimensions / offsets must be multiples of %d and fit", vec);
-  const long waves = (long)B * (C / (lpr * vec));
+  // Long trajectories: 2 or 4 waves per (trajectory, window), at most 8 row iterations each, rows held in registers (a function of L and
+  // the window alone, like the forward pass); longer than that: the one-wave sweep that re-reads its rows.
+  const int rpi = 64 / lpr;
+  int parts = L > 128 ? 4 : (L > 64 ? 2 : 1);
+  int rows_per_part = ((L + parts - 1) / parts + rpi - 1) / rpi * rpi;
+  if ((g_wgrad_force & 8) || (parts > 1 && rows_per_part / rpi > 8)) parts = 1;
+  if (parts == 1) rows_per_part = L;
+  const int nit = (g_wgrad_force & 8) ? 1 << 20 : (rows_per_part + rpi - 1) / rpi;
+  const long waves = (long)B * (C / (lpr * vec)) * parts;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TDX_F32)
-    hipLaunchKernelGGL(groupnorm_act_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, x_ld, (const float*)dy, dy_ld, dy_off,
-                       (float*)dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate);
+    launch_gn_bwd<float>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C,
+                         cpg, lpr, eps, act, accumulate);
   else
-    hipLaunchKernelGGL(groupnorm_act_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, x_ld, (const __bf16*)dy, dy_ld, dy_off,
-                       (__bf16*)dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate);
+    launch_gn_bwd<__bf16>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C,
+                          cpg, lpr, eps, act, accumulate);
   TDX_CHECK_LAUNCH("groupnorm_act_bwd_kernel");
   return TDX_OK;
 }

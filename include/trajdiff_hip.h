@@ -303,6 +303,17 @@ int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t d
                           int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
                           int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
                           void* stream);
+/* nn.GroupNorm + Swish + nn.Dropout(p) in training mode as one pass each way (ResnetBlock.stage2, TrajUNetBlocks.py:83-85): the forward
+ * writes dropout(act(groupnorm(x))) with tdx_dropout's mask for the plain (B, L, C) fp32 output (out_ld == C, out_off == 0; the mask is
+ * keyed by the element index), the backward takes the gradient dy of that output (dy_ld == C, dy_off == 0), regenerates the mask and
+ * otherwise is tdx_groupnorm_act_bwd.  Same results as tdx_groupnorm_act + tdx_dropout and tdx_dropout + tdx_groupnorm_act_bwd. */
+int tdx_groupnorm_act_dropout(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off, const float* gamma, const float* beta,
+                              int32_t B, int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t dtype, float p, uint64_t seed,
+                              uint32_t layer, const int32_t* step_ctr, void* stream);
+int tdx_groupnorm_act_dropout_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                                  int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
+                                  int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype, float p,
+                                  uint64_t seed, uint32_t layer, const int32_t* step_ctr, void* stream);
 
 /* Data gradient of a STRIDE-1 Conv1d: tdx_conv_gemm on dy with the weights of engine.pack_conv_weight_dgrad (taps flipped, channel
  * roles exchanged).  Stride 2 (TrajUNet.py:44): the even input rows see only the centre tap (a k=1 conv of dy with W[:,:,1]^T), the

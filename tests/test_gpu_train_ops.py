@@ -210,6 +210,80 @@ def test_groupnorm_swish_backward(dt, B, L, C, act):
     assert rel(dgam.cpu(), gamma.grad) < 5e-5 and rel(dbet.cpu(), beta.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,L,C", [(3, 200, 128), (2, 100, 256), (5, 64, 128), (2, 300, 128), (3, 13, 1024), (2, 3, 2048)])
+def test_groupnorm_backward_register_and_rereading_forms_agree(B, L, C):
+    """Rows held in registers (split over 2 / 4 waves from L > 64) against the one-wave form that re-reads its rows (test hook bit 8):
+    the same arithmetic; only the association of the sums over the rows differs when a trajectory is split."""
+    _, _lib = _eng()
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(L)
+    x = torch.randn(B, L, C, device="cuda", generator=g) * 2 + 0.3
+    dy = torch.randn(B, L, C, device="cuda", generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(C, device="cuda", generator=g), 0.2 * torch.randn(C, device="cuda", generator=g)
+    out = []
+    for force in (0, 8):
+        old = lib.tdx_conv_wgrad_debug(force)
+        try:
+            dx = torch.randn(B, L, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+            r0, r1 = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+            _lib.check(lib.tdx_groupnorm_act_bwd(x.data_ptr(), C, dy.data_ptr(), C, 0, dx.data_ptr(), C, 0, gam.data_ptr(), bet.data_ptr(), r0.data_ptr(),
+                                                 r1.data_ptr(), B, L, C, 32, 1e-6, 2, 1, _lib.TDX_F32, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            out.append((dx, r0, r1))
+        finally:
+            lib.tdx_conv_wgrad_debug(old)
+    for a, b in zip(*out):
+        assert rel(a, b) < 2e-6
+    if L <= 64 or L == 300:   # one wave per window either way (300 rows: too long for the register form): identical order
+        assert all(torch.equal(a, b) for a, b in zip(*out))
+
+
+@pytest.mark.parametrize("B,L,C,p", [(3, 200, 128, 0.1), (4, 25, 1024, 0.1), (2, 100, 256, 0.5), (5, 13, 1024, 0.0)])
+def test_groupnorm_dropout_in_one_pass_equals_the_two_passes(B, L, C, p):
+    """tdx_groupnorm_act_dropout == tdx_groupnorm_act then tdx_dropout; tdx_groupnorm_act_dropout_bwd == tdx_dropout on the gradient then
+    tdx_groupnorm_act_bwd: bit for bit (same mask, same arithmetic)."""
+    _, _lib = _eng()
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(L)
+    x = torch.randn(B, L, C, device="cuda", generator=g) * 2 + 0.3
+    dy = torch.randn(B, L, C, device="cuda", generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(C, device="cuda", generator=g), 0.2 * torch.randn(C, device="cuda", generator=g)
+    ctr = torch.tensor([7, 0, 0, 0], dtype=torch.int32, device="cuda")
+    seed, layer = 0x1234_5678_9ABC_DEF0, 5
+    y2, y1 = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.tdx_groupnorm_act(x.data_ptr(), C, y2.data_ptr(), C, 0, gam.data_ptr(), bet.data_ptr(), B, L, C, 32, 1e-6, 2, _lib.TDX_F32, st))
+    _lib.check(lib.tdx_dropout(y2.data_ptr(), C, B * L, C, p, seed, layer, ctr.data_ptr(), st))
+    _lib.check(lib.tdx_groupnorm_act_dropout(x.data_ptr(), C, y1.data_ptr(), C, 0, gam.data_ptr(), bet.data_ptr(), B, L, C, 32, 1e-6, 2, _lib.TDX_F32, p, seed,
+                                             layer, ctr.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    if p > 0:
+        zero = float((y1 == 0).float().mean())
+        assert abs(zero - p) < 0.01
+    res = []
+    for fused in (False, True):
+        dx = torch.ones(B, L, C, device="cuda")
+        r0, r1 = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+        args = (x.data_ptr(), C, None, C, 0, dx.data_ptr(), C, 0, gam.data_ptr(), bet.data_ptr(), r0.data_ptr(), r1.data_ptr(), B, L, C, 32, 1e-6, 2, 1, _lib.TDX_F32)
+        if fused:
+            a = list(args)
+            a[2] = dy.data_ptr()
+            _lib.check(lib.tdx_groupnorm_act_dropout_bwd(*a, p, seed, layer, ctr.data_ptr(), st))
+        else:
+            dyd = dy.clone()
+            _lib.check(lib.tdx_dropout(dyd.data_ptr(), C, B * L, C, p, seed, layer, ctr.data_ptr(), st))
+            a = list(args)
+            a[2] = dyd.data_ptr()
+            _lib.check(lib.tdx_groupnorm_act_bwd(*a, st))
+        torch.cuda.synchronize()
+        res.append((dx, r0, r1))
+    assert all(torch.equal(a, b) for a, b in zip(*res))
+    # shapes the fused forms refuse: the mask is keyed by the element index of a plain tensor
+    wide = torch.empty(B, L, C + 16, device="cuda")
+    assert lib.tdx_groupnorm_act_dropout(x.data_ptr(), C, wide.data_ptr(), C + 16, 0, gam.data_ptr(), bet.data_ptr(), B, L, C, 32, 1e-6, 2, _lib.TDX_F32, p, seed,
+                                         layer, ctr.data_ptr(), st) != 0
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("L", [50, 25, 200])
 def test_conv_data_gradient_stride2(dt, L):

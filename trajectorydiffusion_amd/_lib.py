@@ -79,6 +79,9 @@ _SIGNATURES = {
     "tdx_pack_weights": (_i32, [_vp, _i32, _vp]),
     "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
                                      _i32, _i32, _vp]),
+    "tdx_groupnorm_act_dropout": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _f32, _u64, C.c_uint32, _vp, _vp]),
+    "tdx_groupnorm_act_dropout_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,
+                                             _i32, _i32, _f32, _u64, C.c_uint32, _vp, _vp]),
     "tdx_interleave2": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_upsample_fold": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tdx_act_fwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -15,11 +15,19 @@
 namespace {
 
 // NIT = row iterations per lane kept in registers (0: re-read the rows from L2 in each of the three sweeps).
-template <typename T, int NIT, int S>
+// Training-mode nn.Dropout behind the activation (TrajUNetBlocks.py:83-85), DROP = true: the mask of tdx_dropout for the output tensor
+// (Philox4x32-10 keyed by (seed, step_ctr[0], layer) and the element quad (row * C + channel) / 4), applied as the rows are written.
+struct GnDrop {
+  uint32_t thresh, layer;
+  float scale;
+  uint64_t seed;
+  const int32_t* step_ctr;
+};
+template <typename T, int NIT, int S, bool DROP = false>
 __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int out_ld,
                                                            int out_off, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int B, int L, int C, int cpg,
-                                                           int lpr, float eps, int act, int rows_per_part) {
+                                                           int lpr, float eps, int act, int rows_per_part, GnDrop drop = GnDrop{}) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = VEC / 2;
   constexpr int NR = NIT > 0 ? NIT : 1;
@@ -133,16 +141,23 @@ __global__ __launch_bounds__(256) void groupnorm_act_kernel(const T* __restrict_
     Elem<T>::unpack(row(i, l), v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = tdx_act(fmaf(v[j], sc[j], sh[j]), act);
+    if constexpr (DROP) {
+      static_assert(!DROP || VEC == 4, "fused dropout: fp32 rows (one Philox call per 4 channels)");
+      uint32_t r[4];
+      philox4((uint64_t)(((long)b * L + l) * C + ch) >> 2, drop.layer, drop.seed ^ ((uint64_t)(uint32_t)drop.step_ctr[0] << 32), r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = r[j] >= drop.thresh ? v[j] * drop.scale : 0.f;
+    }
     *reinterpret_cast<u32x4*>(ob + (size_t)l * out_ld) = Elem<T>::pack(v);
   }
 }
 
-template <typename T>
+template <typename T, bool DROP = false>
 void launch_gn(int nit, int parts, int rows_per_part, dim3 grid, hipStream_t st, const void* x, int x_ld, void* out, int out_ld, int out_off,
-               const float* gamma, const float* beta, int B, int L, int C, int cpg, int lpr, float eps, int act) {
-#define TDX_GN(N, S)                                                                                                              \
-  hipLaunchKernelGGL((groupnorm_act_kernel<T, N, S>), grid, dim3(256), 0, st, (const T*)x, x_ld, (T*)out, out_ld, out_off, gamma, \
-                     beta, B, L, C, cpg, lpr, eps, act, rows_per_part)
+               const float* gamma, const float* beta, int B, int L, int C, int cpg, int lpr, float eps, int act, GnDrop drop = GnDrop{}) {
+#define TDX_GN(N, S)                                                                                                                    \
+  hipLaunchKernelGGL((groupnorm_act_kernel<T, N, S, DROP>), grid, dim3(256), 0, st, (const T*)x, x_ld, (T*)out, out_ld, out_off, gamma, \
+                     beta, B, L, C, cpg, lpr, eps, act, rows_per_part, drop)
   if (parts == 4) {
     if (nit <= 8) TDX_GN(8, 4);
     else TDX_GN(16, 4);
@@ -199,9 +214,9 @@ extern "C" int tdx_groupnorm_finalize(const float* stats, int32_t stats_ld, int3
   return TDX_OK;
 }
 
-extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
-                                 const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
-                                 int32_t groups, float eps, int32_t act, int32_t dtype, void* stream) {
+static int groupnorm_act_impl(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
+                              const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
+                              int32_t groups, float eps, int32_t act, int32_t dtype, const GnDrop* drop, void* stream) {
   TDX_CHECK_ARG(x && out && gamma && beta, "tdx_groupnorm_act: null pointer");
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_groupnorm_act: bad dtype %d", dtype);
   TDX_CHECK_ARG(B > 0 && L > 0 && C > 0 && groups > 0 && C % groups == 0, "tdx_groupnorm_act: bad shape B=%d L=%d C=%d groups=%d", B, L, C, groups);
@@ -239,10 +254,28 @@ extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t
   dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
   const int nit = (rows_per_part + rpi - 1) / rpi;
-  if (dtype == TDX_F32)
+  if (drop)
+    launch_gn<float, true>(nit, parts, rows_per_part, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act, *drop);
+  else if (dtype == TDX_F32)
     launch_gn<float>(nit, parts, rows_per_part, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   else
     launch_gn<__bf16>(nit, parts, rows_per_part, grid, st, x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, cpg, lpr, eps, act);
   TDX_CHECK_LAUNCH("groupnorm_act_kernel");
   return TDX_OK;
+}
+
+extern "C" int tdx_groupnorm_act(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off,
+                                 const float* gamma, const float* beta, int32_t B, int32_t L, int32_t C,
+                                 int32_t groups, float eps, int32_t act, int32_t dtype, void* stream) {
+  return groupnorm_act_impl(x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, groups, eps, act, dtype, nullptr, stream);
+}
+
+extern "C" int tdx_groupnorm_act_dropout(const void* x, int32_t x_ld, void* out, int32_t out_ld, int32_t out_off, const float* gamma,
+                                         const float* beta, int32_t B, int32_t L, int32_t C, int32_t groups, float eps, int32_t act,
+                                         int32_t dtype, float p, uint64_t seed, uint32_t layer, const int32_t* step_ctr, void* stream) {
+  TDX_CHECK_ARG(dtype == TDX_F32, "tdx_groupnorm_act_dropout: fp32 rows only (dtype %d)", dtype);
+  TDX_CHECK_ARG(step_ctr && p >= 0.f && p < 1.f, "tdx_groupnorm_act_dropout: p=%f not in [0, 1) or no step counter", (double)p);
+  TDX_CHECK_ARG(out_off == 0 && out_ld == C, "tdx_groupnorm_act_dropout: the mask is keyed by the element index of a plain (B, L, C) output");
+  const GnDrop d{(uint32_t)((double)p * 4294967296.0), layer, 1.0f / (1.0f - p), seed, step_ctr};
+  return groupnorm_act_impl(x, x_ld, out, out_ld, out_off, gamma, beta, B, L, C, groups, eps, act, dtype, &d, stream);
 }

@@ -445,14 +445,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __res
 // registers; a sweep that re-reads its rows pays one dependent memory round trip per row iteration, 100 of them at L = 200, and
 // that latency, not the 315 MB of traffic, was the kernel's time (0.13 ms per full-resolution layer).  NIT == 0: the re-reading
 // form, for trajectories too long for the register file.  Same arithmetic and summation order in both.
-template <typename T, int NIT, int S>
+// DROP: dy is the gradient of dropout(act(...)): the mask of the forward pass (tdx_groupnorm_act_dropout, i.e. tdx_dropout's for the
+// (B, L, C) tensor dy belongs to) is regenerated and applied as dy is read.
+struct GnDropB {
+  uint32_t thresh, layer;
+  float scale;
+  uint64_t seed;
+  const int32_t* step_ctr;
+};
+template <typename T, int NIT, int S, bool DROP>
 __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
                                                                int dy_off, T* __restrict__ dx, int dx_ld, int dx_off,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ dgamma_rows, float* __restrict__ dbeta_rows, int B,
                                                                int L, int C, int cpg, int lpr, float eps, int act, int accumulate,
-                                                               int rows_per_part) {
+                                                               int rows_per_part, GnDropB drop) {
   constexpr int VEC = Elem<T>::kVec;
+  static_assert(!DROP || VEC == 4, "fused dropout: fp32 rows (one Philox call per 4 channels)");
   constexpr int H = VEC / 2;
   constexpr int NR = NIT > 0 ? NIT : 1;
   constexpr bool KEEP = NIT > 0 && sizeof(T) == 4;   // fp32 rows in registers: exact to overwrite dy with dxh
@@ -524,13 +533,36 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
       hg[i] = l < L1 ? *reinterpret_cast<const u32x4*>(dyb + (size_t)l * dy_ld) : (u32x4){0u, 0u, 0u, 0u};
     }
   }
+  auto mask = [&](int l, float (&g)[VEC]) {
+    if constexpr (DROP) {
+      uint32_t r[4];
+      philox4((uint64_t)(((long)b * L + l) * C + ch) >> 2, drop.layer, drop.seed ^ ((uint64_t)(uint32_t)drop.step_ctr[0] << 32), r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = r[j] >= drop.thresh ? g[j] * drop.scale : 0.f;
+    }
+  };
+  if constexpr (DROP && NIT > 0) {   // once, in the registers
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int l = l0 + rl + i * rpi;
+      if (l < L1) {
+        float g[VEC];
+        Elem<T>::unpack(hg[i], g);
+        mask(l, g);
+        hg[i] = Elem<T>::pack(g);
+      }
+    }
+  }
   auto xrow = [&](int i, int l, float (&v)[VEC]) {
     if constexpr (NIT > 0) Elem<T>::unpack(hx[i], v);
     else Elem<T>::unpack(*reinterpret_cast<const u32x4*>(xb + (size_t)l * x_ld), v);
   };
   auto grow = [&](int i, int l, float (&v)[VEC]) {
     if constexpr (NIT > 0) Elem<T>::unpack(hg[i], v);
-    else Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dyb + (size_t)l * dy_ld), v);
+    else {
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dyb + (size_t)l * dy_ld), v);
+      mask(l, v);
+    }
   };
   const int nit = NIT > 0 ? NIT : (L - rl + rpi - 1) / rpi;   // (NIT == 0 only with S == 1: l0 = 0, L1 = L)
   const float inv_cnt = 1.0f / ((float)cpg * (float)L);
@@ -699,13 +731,13 @@ __global__ __launch_bounds__(256) void groupnorm_act_bwd_kernel(const T* __restr
   }
 }
 
-template <typename T>
+template <typename T, bool DROP>
 void launch_gn_bwd(int nit, int parts, int rows_per_part, dim3 grid, hipStream_t st, const void* x, int x_ld, const void* dy, int dy_ld, int dy_off,
                    void* dx, int dx_ld, int dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int B, int L, int C,
-                   int cpg, int lpr, float eps, int act, int accumulate) {
-#define TDX_GNB(N, S)                                                                                                                            \
-  hipLaunchKernelGGL((groupnorm_act_bwd_kernel<T, N, S>), grid, dim3(256), 0, st, (const T*)x, x_ld, (const T*)dy, dy_ld, dy_off, (T*)dx, dx_ld, \
-                     dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate, rows_per_part)
+                   int cpg, int lpr, float eps, int act, int accumulate, GnDropB drop) {
+#define TDX_GNB(N, S)                                                                                                                                  \
+  hipLaunchKernelGGL((groupnorm_act_bwd_kernel<T, N, S, DROP>), grid, dim3(256), 0, st, (const T*)x, x_ld, (const T*)dy, dy_ld, dy_off, (T*)dx, dx_ld, \
+                     dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, cpg, lpr, eps, act, accumulate, rows_per_part, drop)
   if (parts == 4) TDX_GNB(8, 4);
   else if (parts == 2) TDX_GNB(8, 2);
   else if (nit <= 2) TDX_GNB(2, 1);
@@ -1209,10 +1241,10 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   return TDX_OK;
 }
 
-extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
-                                     int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
-                                     int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
-                                     void* stream) {
+static int groupnorm_act_bwd_impl(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                                  int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
+                                  int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
+                                  const GnDropB* drop, void* stream) {
   TDX_CHECK_ARG(x && dy && dx && gamma && beta && dgamma_rows && dbeta_rows, "tdx_groupnorm_act_bwd: null pointer");
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_groupnorm_act_bwd: bad dtype %d", dtype);
   TDX_CHECK_ARG(B > 0 && L > 0 && C > 0 && groups > 0 && C % groups == 0, "tdx_groupnorm_act_bwd: bad shape B=%d L=%d C=%d groups=%d", B, L, C, groups);
@@ -1239,14 +1271,37 @@ extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy
   const long waves = (long)B * (C / (lpr * vec)) * parts;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TDX_F32)
-    launch_gn_bwd<float>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C,
-                         cpg, lpr, eps, act, accumulate);
+  if (drop)
+    launch_gn_bwd<float, true>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B,
+                               L, C, cpg, lpr, eps, act, accumulate, *drop);
+  else if (dtype == TDX_F32)
+    launch_gn_bwd<float, false>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B,
+                                L, C, cpg, lpr, eps, act, accumulate, GnDropB{});
   else
-    launch_gn_bwd<__bf16>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C,
-                          cpg, lpr, eps, act, accumulate);
+    launch_gn_bwd<__bf16, false>(nit, parts, rows_per_part, grid, st, x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B,
+                                 L, C, cpg, lpr, eps, act, accumulate, GnDropB{});
   TDX_CHECK_LAUNCH("groupnorm_act_bwd_kernel");
   return TDX_OK;
+}
+
+extern "C" int tdx_groupnorm_act_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                                     int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows, int32_t B,
+                                     int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate, int32_t dtype,
+                                     void* stream) {
+  return groupnorm_act_bwd_impl(x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, groups, eps, act, accumulate,
+                                dtype, nullptr, stream);
+}
+
+extern "C" int tdx_groupnorm_act_dropout_bwd(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,
+                                             int32_t dx_off, const float* gamma, const float* beta, float* dgamma_rows, float* dbeta_rows,
+                                             int32_t B, int32_t L, int32_t C, int32_t groups, float eps, int32_t act, int32_t accumulate,
+                                             int32_t dtype, float p, uint64_t seed, uint32_t layer, const int32_t* step_ctr, void* stream) {
+  TDX_CHECK_ARG(dtype == TDX_F32, "tdx_groupnorm_act_dropout_bwd: fp32 rows only (dtype %d)", dtype);
+  TDX_CHECK_ARG(step_ctr && p >= 0.f && p < 1.f, "tdx_groupnorm_act_dropout_bwd: p=%f not in [0, 1) or no step counter", (double)p);
+  TDX_CHECK_ARG(dy_off == 0 && dy_ld == C, "tdx_groupnorm_act_dropout_bwd: the mask is keyed by the element index of a plain (B, L, C) gradient");
+  const GnDropB d{(uint32_t)((double)p * 4294967296.0), layer, 1.0f / (1.0f - p), seed, step_ctr};
+  return groupnorm_act_bwd_impl(x, x_ld, dy, dy_ld, dy_off, dx, dx_ld, dx_off, gamma, beta, dgamma_rows, dbeta_rows, B, L, C, groups, eps, act, accumulate,
+                                dtype, &d, stream);
 }
 
 extern "C" int tdx_interleave2(const void* even, const void* odd, void* out, int32_t out_ld, int32_t out_off, int32_t B, int32_t L, int32_t C,

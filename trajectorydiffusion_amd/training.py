@@ -279,17 +279,29 @@ class TrainStep:
                             res=gs[..., s.ch_off:], res_ld=s.ld, name=name + ".dgrad")
         self._back.append(backward)
 
-    def gn(self, name: str, x: torch.Tensor, Cn: int, L: int, out: torch.Tensor, out_off: int, mod, p_off: int, groups: int, act: int) -> None:
+    def gn(self, name: str, x: torch.Tensor, Cn: int, L: int, out: torch.Tensor, out_off: int, mod, p_off: int, groups: int, act: int,
+           drop: Optional[Tuple[float, int]] = None) -> None:
+        """GroupNorm (+ activation); drop = (p, layer): nn.Dropout(p) behind it in the same pass, forward and backward (tdx_dropout's mask
+        for `out`, which must then be the plain (B, L, Cn) tensor)."""
         B, lib = self.B, self.lib
         gam, bet = mod.weight, mod.bias
-        self.fw.groupnorm(x, x.shape[-1], out, out.shape[-1], out_off, gam.data, bet.data, p_off, B, L, Cn, groups, mod.eps, act, name=name)
+        if drop is None:
+            self.fw.groupnorm(x, x.shape[-1], out, out.shape[-1], out_off, gam.data, bet.data, p_off, B, L, Cn, groups, mod.eps, act, name=name)
+        else:
+            self.fw.call(name, lib.tdx_groupnorm_act_dropout, x.data_ptr(), x.shape[-1], out.data_ptr(), out.shape[-1], out_off,
+                         gam.data.data_ptr() + 4 * p_off, bet.data.data_ptr() + 4 * p_off, B, L, Cn, groups, mod.eps, act, F32, drop[0], self.seed, drop[1],
+                         self.rng.data_ptr(), keep=[x, out, gam.data, bet.data])
 
         def backward():
             ra, rb = self._new(B, Cn), self._new(B, Cn)
             go, gx = self.G(out), self.G(x)
-            self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_bwd, x.data_ptr(), x.shape[-1], go.data_ptr(), out.shape[-1], out_off, gx.data_ptr(),
-                         x.shape[-1], 0, gam.data.data_ptr() + 4 * p_off, bet.data.data_ptr() + 4 * p_off, ra.data_ptr(), rb.data_ptr(), B, L, Cn, groups,
-                         mod.eps, act, 0 if self.first_write(x, 0, Cn) else 1, F32)
+            args = (x.data_ptr(), x.shape[-1], go.data_ptr(), out.shape[-1], out_off, gx.data_ptr(),
+                    x.shape[-1], 0, gam.data.data_ptr() + 4 * p_off, bet.data.data_ptr() + 4 * p_off, ra.data_ptr(), rb.data_ptr(), B, L, Cn, groups,
+                    mod.eps, act, 0 if self.first_write(x, 0, Cn) else 1, F32)
+            if drop is None:
+                self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_bwd, *args)
+            else:
+                self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_dropout_bwd, *args, drop[0], self.seed, drop[1], self.rng.data_ptr())
             for rows, p in ((ra, gam), (rb, bet)):
                 self.bw.call(name + ".dparam", lib.tdx_colsum, rows.data_ptr(), Cn, B, Cn, self.PG(p).data_ptr() + 4 * p_off, 1, F32, self.red_ws.data_ptr())
         self._back.append(backward)
@@ -308,11 +320,13 @@ class TrainStep:
         self.conv(key + "conv1", [_Src(a1, cin, L, blk.stage1[2].weight)], cout, L, h, biases=[blk.stage1[2].bias],
                   ebias=(self.E, self.m.embed_offsets[key]))
         a2 = self._new(B, L, cout)
-        self.gn(key + "gn2", h, cout, L, a2, 0, blk.stage2[0], 0, blk.norm_groups, ACT_SWISH)
         p = blk.dropout if self.dropout is None else self.dropout
-        if p > 0.0:   # nn.Dropout in stage2 (TrajUNetBlocks.py:85); the same call on the gradient is its backward
+        fuse = os.environ.get("TDX_TRAIN_FUSE_DROPOUT", "1") != "0"
+        if p > 0.0:
             self._layer += 1
-            layer = self._layer
+        layer = self._layer
+        self.gn(key + "gn2", h, cout, L, a2, 0, blk.stage2[0], 0, blk.norm_groups, ACT_SWISH, drop=(p, layer) if p > 0.0 and fuse else None)
+        if p > 0.0 and not fuse:   # nn.Dropout in stage2 (TrajUNetBlocks.py:85) as its own pass; the same call on the gradient is its backward
             self.fw.call(key + "dropout", self.lib.tdx_dropout, a2.data_ptr(), cout, B * L, cout, p, self.seed, layer, self.rng.data_ptr())
             self._back.append(lambda: self.bw.call(key + "dropout.bwd", self.lib.tdx_dropout, self.G(a2).data_ptr(), cout, B * L, cout, p, self.seed,
                                                    layer, self.rng.data_ptr()))

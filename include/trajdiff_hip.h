@@ -261,6 +261,12 @@ int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int3
 int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
                    float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
                    void* stream);
+/* The same, plus the bias gradient dbias[co] (+)= sum over all rows of dY[n][co] (nn.Conv1d's bias, TrajUNetBlocks.py:77,86,89) from the
+ * same launch where the large-tile kernel runs (it sums the columns of the dY rows it stages anyway: no second 100 MB read of dY);
+ * every other shape runs tdx_colsum first, through the same workspace (ws_floats >= tdx_train_workspace_floats() then). */
+int tdx_conv_wgrad_bias(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout, float* dw,
+                        int32_t cin_total, int32_t ci_off, int32_t accumulate, float* dbias, int32_t dbias_accumulate, int32_t dtype, float* ws,
+                        int64_t ws_floats, void* stream);
 /* ---- Evaluation metrics over sampled trajectories (eval_trajunet.ipynb cell 12; next-row widening) ----------
  * Workspace for the calls below: tdx_metric_workspace_bytes(number of histogram bins) bytes of device memory. */
 int64_t tdx_metric_workspace_bytes(int32_t n_bins_total);

@@ -158,6 +158,33 @@ def test_conv_weight_gradient(dt, case):
                                              _lib.dtype_code(dt), small.data_ptr(), 16, _lib.stream_ptr()))
 
 
+@pytest.mark.parametrize("B,L,cin,cout,taps", [(8, 200, 128, 128, 3), (64, 25, 256, 384, 3), (16, 13, 128, 256, 1), (4, 50, 64, 96, 3), (3, 7, 128, 128, 3)])
+def test_conv_weight_gradient_with_bias_gradient(B, L, cin, cout, taps):
+    """tdx_conv_wgrad_bias: dW bit-identical to tdx_conv_wgrad, dbias = column sums of dY (tdx_colsum's value up to the order of the sum),
+    accumulate honoured; large-tile shapes take the sums from the weight-gradient kernel, the others from tdx_colsum."""
+    _, _lib = _eng()
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(cin + L)
+    x = torch.randn(B, L, cin, device="cuda", generator=g)
+    dy = torch.randn(B, L, cout + 8, device="cuda", generator=g)
+    k = _lib.KSeg(x.data_ptr(), 0.0, 0, cin, 0, cin, taps, 1, L, L, 0)
+    ws = workspace(64 << 20)
+    dw0, dw1 = torch.zeros(cout, cin * taps, device="cuda"), torch.zeros(cout, cin * taps, device="cuda")
+    db = torch.full((cout,), 2.0, device="cuda")
+    _lib.check(lib.tdx_conv_wgrad(dy.data_ptr(), cout + 8, 8, cout, ctypes.byref(k), B, L, dw0.data_ptr(), cin, 0, 0, _lib.TDX_F32, ws.data_ptr(), ws.numel(), st))
+    _lib.check(lib.tdx_conv_wgrad_bias(dy.data_ptr(), cout + 8, 8, cout, ctypes.byref(k), B, L, dw1.data_ptr(), cin, 0, 0, db.data_ptr(), 1, _lib.TDX_F32,
+                                       ws.data_ptr(), ws.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1)
+    want = dy[:, :, 8:].double().sum(dim=(0, 1)) + 2.0
+    assert float((db.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    db2 = torch.empty(cout, device="cuda")
+    _lib.check(lib.tdx_conv_wgrad_bias(dy.data_ptr(), cout + 8, 8, cout, ctypes.byref(k), B, L, dw1.data_ptr(), cin, 0, 0, db2.data_ptr(), 0, _lib.TDX_F32,
+                                       ws.data_ptr(), ws.numel(), st))
+    torch.cuda.synchronize()
+    assert float((db2.double() - (want - 2.0)).abs().max()) < 1e-4 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("k", [3, 1])
 def test_conv_data_gradient_is_the_forward_kernel_on_flipped_weights(dt, k):

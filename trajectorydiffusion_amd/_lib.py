@@ -75,6 +75,7 @@ _SIGNATURES = {
     "tdx_mse_loss_grad_static": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "tdx_colsum": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "tdx_conv_wgrad_bias": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "tdx_conv_wgrad_debug": (_i32, [_i32]),
     "tdx_pack_weights": (_i32, [_vp, _i32, _vp]),
     "tdx_groupnorm_act_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32,

@@ -192,6 +192,7 @@ struct WgradArgs {
   float up_scale;
   int32_t N, lout, rows_per_split;
   float* part;  // [splits][cout][cin * taps]
+  float* bias_part;  // [splits][cout] column sums of dY per slab (large-tile kernel only), or null
 };
 
 template <typename T>
@@ -287,6 +288,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) 
       for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   f32x4 dreg[2], xreg[XV];
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};   // bias gradient: this thread's share of the column sums of dY (rows tid / 32 and + 16 of every chunk)
+  const bool want_bias = p.bias_part != nullptr && blockIdx.y == 0;
   int freg = 0;
   auto fetch = [&](int r0) {
 #pragma unroll
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) 
       const int e = tid + q * 512;
       *reinterpret_cast<f32x4*>(&dys[(e >> 5) * LD + (e & 31) * 4]) = dreg[q];
     }
+    if (want_bias) bsum = (bsum + dreg[0]) + dreg[1];   // (rows past the slab were fetched as zeros)
 #pragma unroll
     for (int q = 0; q < XV; ++q) {
       const int e = tid + q * 512;
@@ -381,6 +385,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(const WgradArgs p) 
           const int co = co0 + cob + i * 16 + 4 * lk + r, ci = ci0 + cib + j * 16 + l16;
           p.part[((size_t)split * p.cout + co) * kdim + ci * TAPS + t] = acc[t][i][j][r];
         }
+  if (want_bias) {   // the 16 row classes of a column quad, added in order (the K loop's last barrier has released dys)
+    *reinterpret_cast<f32x4*>(&dys[(tid >> 5) * LD + (tid & 31) * 4]) = bsum;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(&dys[tid * 4]);
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t = t + *reinterpret_cast<const f32x4*>(&dys[k * LD + tid * 4]);
+      *reinterpret_cast<f32x4*>(p.bias_part + (size_t)split * p.cout + co0 + tid * 4) = t;
+    }
+  }
 #endif
 }
 
@@ -401,13 +415,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // (128 x 384 values) is cut into 512 slabs, and one thread per output walking them one after the other is 192 workgroups each
 // waiting for 512 dependent-latency loads (0.13 ms for 100 MB).  Block = 16 float4 columns x 16 classes; class q adds slabs
 // q, q + 16, ... in order, then the classes are added in order: a fixed association for a given slab count, no atomics.
+// Blocks past the gradient's own (blockIdx.x >= wblocks) do the same for the bias gradient's slab sums (bias_part [splits][cout], cout a
+// multiple of 4), so that tdx_conv_wgrad_bias needs no third launch.
 __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __restrict__ part, int splits, int cout, int kdim4,
-                                                             float* __restrict__ dw, int ld4, int off4, int accumulate) {
+                                                             float* __restrict__ dw, int ld4, int off4, int accumulate, int wblocks,
+                                                             const float* __restrict__ bias_part, float* __restrict__ dbias, int bias_accumulate) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ f32x4 red[16][16];
+  if ((int)blockIdx.x >= wblocks) {   // (block-uniform)
+    part = bias_part;
+    dw = dbias;
+    kdim4 = cout >> 2;
+    cout = 1;
+    ld4 = off4 = 0;
+    accumulate = bias_accumulate;
+  }
   const long total4 = (long)cout * kdim4;
   const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const long i = (long)blockIdx.x * 16 + c;
+  const long i = (long)((int)blockIdx.x >= wblocks ? (int)blockIdx.x - wblocks : (int)blockIdx.x) * 16 + c;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (i < total4) {
     const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
@@ -1176,9 +1201,9 @@ static int wgrad_cus() {   // CUs of the current device (per device: a process m
   return n;
 }
 
-extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
-                              float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
-                              void* stream) {
+static int conv_wgrad_impl(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
+                           float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
+                           float* dbias, int32_t dbias_accumulate, void* stream) {
   TDX_CHECK_ARG(dy && seg && seg->src && dw && ws, "tdx_conv_wgrad: null pointer");
   TDX_CHECK_ARG(dtype == TDX_F32 || dtype == TDX_BF16, "tdx_conv_wgrad: bad dtype %d", dtype);
   TDX_CHECK_ARG(B > 0 && lout > 0 && cout > 0 && dy_off >= 0 && dy_off + cout <= dy_ld, "tdx_conv_wgrad: bad dY shape");
@@ -1215,11 +1240,19 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
     splits = std::max(std::min(64, (N + 2047) / 2048), std::min(512, 2048 / tiles));
     splits = std::max(1, std::min(splits, (N + 255) / 256));
   }
-  if ((int64_t)splits * per_split > ws_floats) splits = (int)(ws_floats / per_split);
-  TDX_CHECK_ARG(splits >= 1, "tdx_conv_wgrad: workspace of %lld floats is smaller than one gradient (%lld)", (long long)ws_floats, (long long)per_split);
+  const bool bias_here = dbias && big;   // the large-tile kernel sums the columns of the dY rows it stages anyway
+  if (dbias && !big) {                   // every other shape: the stand-alone column sum first (it is done with ws before the slabs are written)
+    TDX_CHECK_ARG(ws_floats >= (int64_t)kRedBlocks * 4096, "tdx_conv_wgrad_bias: workspace smaller than tdx_train_workspace_floats()");
+    const int rc = tdx_colsum((const char*)dy + (size_t)dy_off * (dtype == TDX_F32 ? 4 : 2), dy_ld, N, cout, dbias, dbias_accumulate, dtype, ws, stream);
+    if (rc != TDX_OK) return rc;
+  }
+  const int64_t per_slab = per_split + (bias_here ? cout : 0);
+  if ((int64_t)splits * per_slab > ws_floats) splits = (int)(ws_floats / per_slab);
+  TDX_CHECK_ARG(splits >= 1, "tdx_conv_wgrad: workspace of %lld floats is smaller than one gradient (%lld)", (long long)ws_floats, (long long)per_slab);
   WgradArgs a{(const char*)dy, (const char*)s.src, dy_ld, dy_off, cout, s.src_ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt,
-              s.lvirt != s.lin ? s.up_scale : 0.f, N, lout, ((N + splits - 1) / splits + 31) / 32 * 32, ws};
+              s.lvirt != s.lin ? s.up_scale : 0.f, N, lout, ((N + splits - 1) / splits + 31) / 32 * 32, ws, nullptr};
   splits = (N + a.rows_per_split - 1) / a.rows_per_split;
+  if (bias_here) a.bias_part = ws + (size_t)splits * per_split;   // (per_split is a multiple of 4 floats here: 16-byte aligned like ws)
   if (big) {
     const dim3 grid((unsigned)(cout / 128), (unsigned)(s.cin / 128), (unsigned)splits);
     if (s2) hipLaunchKernelGGL((conv_wgrad_big_kernel<3, true>), grid, dim3(512), 0, st, a);
@@ -1232,13 +1265,32 @@ extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int
   }
   const int kdim = s.cin * s.taps;
   if (!(g_wgrad_force & 2) && kdim % 4 == 0 && (cin_total * s.taps) % 4 == 0 && (ci_off * s.taps) % 4 == 0 && ((uintptr_t)dw & 15) == 0 && ((uintptr_t)ws & 15) == 0)
-    hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)((per_split / 4 + 15) / 16)), dim3(256), 0, st, ws, splits, cout, kdim / 4, dw,
-                       cin_total * s.taps / 4, ci_off * s.taps / 4, accumulate);
-  else
+  {
+    const int wblocks = (int)((per_split / 4 + 15) / 16), bblocks = bias_here && ((uintptr_t)dbias & 15) == 0 ? (cout / 4 + 15) / 16 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, ws, splits, cout, kdim / 4, dw,
+                       cin_total * s.taps / 4, ci_off * s.taps / 4, accumulate, wblocks, a.bias_part, dbias, dbias_accumulate);
+    if (bias_here && !bblocks)
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cout + 15) / 16)), dim3(256), 0, st, a.bias_part, splits, cout, dbias, dbias_accumulate);
+  } else {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256), 0, st, ws, splits, cout, s.cin, s.taps, dw,
                        cin_total, ci_off, accumulate);
+    if (bias_here) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cout + 15) / 16)), dim3(256), 0, st, a.bias_part, splits, cout, dbias, dbias_accumulate);
+  }
   TDX_CHECK_LAUNCH("conv_wgrad");
   return TDX_OK;
+}
+
+extern "C" int tdx_conv_wgrad(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
+                              float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, int32_t dtype, float* ws, int64_t ws_floats,
+                              void* stream) {
+  return conv_wgrad_impl(dy, dy_ld, dy_off, cout, seg, B, lout, dw, cin_total, ci_off, accumulate, dtype, ws, ws_floats, nullptr, 0, stream);
+}
+
+extern "C" int tdx_conv_wgrad_bias(const void* dy, int32_t dy_ld, int32_t dy_off, int32_t cout, const tdx_kseg* seg, int32_t B, int32_t lout,
+                                   float* dw, int32_t cin_total, int32_t ci_off, int32_t accumulate, float* dbias, int32_t dbias_accumulate,
+                                   int32_t dtype, float* ws, int64_t ws_floats, void* stream) {
+  TDX_CHECK_ARG(dbias, "tdx_conv_wgrad_bias: null dbias");
+  return conv_wgrad_impl(dy, dy_ld, dy_off, cout, seg, B, lout, dw, cin_total, ci_off, accumulate, dtype, ws, ws_floats, dbias, dbias_accumulate, stream);
 }
 
 static int groupnorm_act_bwd_impl(const void* x, int32_t x_ld, const void* dy, int32_t dy_ld, int32_t dy_off, void* dx, int32_t dx_ld,

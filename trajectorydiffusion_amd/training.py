@@ -247,8 +247,12 @@ class TrainStep:
                 gr = self.G(res)
                 bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout,
                         0 if self.first_write(res, 0, cout) else 1, F32)
+            # the first bias takes its gradient from the first segment's weight-gradient launch (tdx_conv_wgrad_bias); a second bias (the
+            # 1x1 shortcut's, same gradient) keeps the stand-alone column sum
+            fused_bias = biases[0] if biases and os.environ.get("TDX_TRAIN_FUSE_DBIAS", "1") != "0" else None
             for b in biases:
-                bw.call(name + ".dbias", lib.tdx_colsum, gptr, ld, N, cout, self.PG(b).data_ptr(), 1, F32, self.red_ws.data_ptr())
+                if b is not fused_bias:
+                    bw.call(name + ".dbias", lib.tdx_colsum, gptr, ld, N, cout, self.PG(b).data_ptr(), 1, F32, self.red_ws.data_ptr())
             if ebias is not None:
                 ge = self.G(ebias[0])
                 bw.call(name + ".debias", lib.tdx_traj_rowsum, gptr, ld, ge.data_ptr() + 4 * ebias[1], ge.shape[-1], B, lout, cout, 1)
@@ -257,8 +261,13 @@ class TrainStep:
                          0, s.ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt, 0)
                 self._keep.append(k)
                 gw = self.PG(s.W)
-                bw.call(name + ".wgrad", lib.tdx_conv_wgrad, go.data_ptr(), ld, off, cout, C.byref(k), B, lout, gw.data_ptr(), s.W.shape[1], s.w_off, 1,
-                        F32, self.ws.data_ptr(), self.ws.numel())
+                if fused_bias is not None:
+                    bw.call(name + ".wgrad", lib.tdx_conv_wgrad_bias, go.data_ptr(), ld, off, cout, C.byref(k), B, lout, gw.data_ptr(), s.W.shape[1],
+                            s.w_off, 1, self.PG(fused_bias).data_ptr(), 1, F32, self.ws.data_ptr(), self.ws.numel())
+                    fused_bias = None
+                else:
+                    bw.call(name + ".wgrad", lib.tdx_conv_wgrad, go.data_ptr(), ld, off, cout, C.byref(k), B, lout, gw.data_ptr(), s.W.shape[1], s.w_off,
+                            1, F32, self.ws.data_ptr(), self.ws.numel())
                 if wd is None:
                     continue
                 gs = self.G(s.t)

@@ -252,6 +252,10 @@ int tdx_mse_loss_grad_static(const float* pred, const float* target, float* dpre
 /* out[c] (+)= sum over the n rows of x[r * ld + c], c < C <= 4096: bias gradients of Conv1d / Linear, and dgamma / dbeta from the
  * per-trajectory rows of tdx_groupnorm_act_bwd. */
 int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float* out, int32_t accumulate, int32_t dtype, float* ws, void* stream);
+/* Two matrices of one shape in one launch pair (GroupNorm's dgamma and dbeta rows, tdx_groupnorm_act_bwd): outa (+)= column sums of xa,
+ * outb (+)= column sums of xb; the same sums, in the same order, as two tdx_colsum calls. */
+int tdx_colsum_pair(const void* xa, const void* xb, int32_t ld, int32_t n, int32_t c, float* outa, float* outb, int32_t accumulate, int32_t dtype,
+                    float* ws, void* stream);
 
 /* Weight gradient of one K-segment of tdx_conv_gemm (autograd of nn.Conv1d, TrajUNetBlocks.py:77,86,89):
  *   dw[co][ci_off + ci][t] (+)= sum over output rows n of dy[n * dy_ld + dy_off + co] * X[src(n, t)][ci],

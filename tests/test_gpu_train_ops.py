@@ -84,6 +84,24 @@ def test_colsum(dt, n, c):
         assert rel(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("n,c", [(1024, 128), (1024, 1024), (37, 32), (4096, 2048), (100, 6)])
+def test_colsum_pair_is_two_colsums(n, c):
+    _, _lib = _eng()
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(n + c)
+    xa, xb = torch.randn(n, c, device="cuda", generator=g), torch.randn(n, c, device="cuda", generator=g)
+    ws = workspace()
+    for acc in (0, 1):
+        oa, ob = torch.full((c,), 3.0, device="cuda"), torch.full((c,), -1.0, device="cuda")
+        pa, pb = oa.clone(), ob.clone()
+        _lib.check(lib.tdx_colsum(xa.data_ptr(), c, n, c, oa.data_ptr(), acc, _lib.TDX_F32, ws.data_ptr(), st))
+        _lib.check(lib.tdx_colsum(xb.data_ptr(), c, n, c, ob.data_ptr(), acc, _lib.TDX_F32, ws.data_ptr(), st))
+        _lib.check(lib.tdx_colsum_pair(xa.data_ptr(), xb.data_ptr(), c, n, c, pa.data_ptr(), pb.data_ptr(), acc, _lib.TDX_F32, ws.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(oa, pa) and torch.equal(ob, pb)
+        assert rel(pa.cpu().double(), xa.cpu().double().sum(0) + (3.0 if acc else 0.0)) < 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("case", ["k3", "k3_s2", "k3_up", "k1", "concat_half", "ragged", "big_k3", "big_up", "big_k1", "big_concat", "big_short",
                                   "big_one_row", "big_s2", "big_s2_odd"])

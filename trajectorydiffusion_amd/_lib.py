@@ -74,6 +74,7 @@ _SIGNATURES = {
     "tdx_mse_loss_grad": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tdx_mse_loss_grad_static": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "tdx_colsum": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "tdx_colsum_pair": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "tdx_conv_wgrad": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "tdx_conv_wgrad_bias": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(KSeg), _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "tdx_conv_wgrad_debug": (_i32, [_i32]),

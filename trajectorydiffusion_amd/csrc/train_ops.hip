@@ -49,8 +49,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // shuffles, the four waves through LDS.  Anything else: the scalar kernel below.
 template <int UNROLL>
 __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ x, int ld, int n, int c, int lpr,
-                                                               float* __restrict__ part, int rows_per_slab) {
+                                                               float* __restrict__ part, int rows_per_slab, const float* __restrict__ x2) {
   __shared__ f32x4 red[4][64];
+  if (blockIdx.z) {   // second matrix of a pair (tdx_colsum_pair): its partials follow the first one's
+    x = x2;
+    part += (size_t)gridDim.x * c;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rpw = 64 / lpr;                                  // rows one wave covers per load
   const int col = blockIdx.y * 256 + (lane % lpr) * 4;       // (lpr = min(64, c / 4): windows only exist when lpr == 64)
@@ -93,8 +97,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   if (sub == 0 && col < c) part[(size_t)blockIdx.x * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // block = 16 columns x 16 slab classes; class q adds slabs q, q + 16, ... in order, then the classes are added in order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int slabs, int c, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int slabs, int c, float* __restrict__ out, int accumulate,
+                                                          float* __restrict__ out2 = nullptr) {
   __shared__ float red[16][17];
+  if (blockIdx.y) {
+    part += (size_t)slabs * c;
+    out = out2;
+  }
   const int cj = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + cj;
   float acc = 0.f;
@@ -1161,8 +1170,8 @@ extern "C" int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float
       const int rows_per_slab = ((n + slabs - 1) / slabs + rows_iter - 1) / rows_iter * rows_iter;
       slabs = (n + rows_per_slab - 1) / rows_per_slab;
       hipLaunchKernelGGL(colsum_partial_v4_kernel<4>, dim3((unsigned)slabs, (unsigned)windows), dim3(256), 0, st, (const float*)x, ld, n, c, lpr,
-                         ws, rows_per_slab);
-      hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
+                         ws, rows_per_slab, (const float*)nullptr);
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, ws, slabs, c, out, accumulate, (float*)nullptr);
       TDX_CHECK_LAUNCH("colsum");
       return TDX_OK;
     }
@@ -1174,6 +1183,28 @@ extern "C" int tdx_colsum(const void* x, int32_t ld, int32_t n, int32_t c, float
   else hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, ld, n, c, ws, slabs);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, ws, slabs, c, out, accumulate);
   TDX_CHECK_LAUNCH("colsum");
+  return TDX_OK;
+}
+
+extern "C" int tdx_colsum_pair(const void* xa, const void* xb, int32_t ld, int32_t n, int32_t c, float* outa, float* outb, int32_t accumulate,
+                               int32_t dtype, float* ws, void* stream) {
+  TDX_CHECK_ARG(xa && xb && outa && outb && ws && n > 0 && c > 0 && ld >= c, "tdx_colsum_pair: bad arguments n=%d c=%d ld=%d", n, c, ld);
+  const int lpr = c >= 256 ? 64 : c / 4;
+  const bool v4 = dtype == TDX_F32 && c % 4 == 0 && ld % 4 == 0 && (((uintptr_t)xa | (uintptr_t)xb) & 15) == 0 && (c <= 256 || c % 256 == 0) && c <= 4096 &&
+                  lpr > 0 && (lpr & (lpr - 1)) == 0;
+  if (!v4) {   // shapes outside the 16-byte-load kernel: one after the other
+    const int rc = tdx_colsum(xa, ld, n, c, outa, accumulate, dtype, ws, stream);
+    return rc != TDX_OK ? rc : tdx_colsum(xb, ld, n, c, outb, accumulate, dtype, ws, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int windows = (c + 255) / 256, rows_iter = 4 * (64 / lpr);
+  int slabs = std::max(1, std::min(kRedBlocks / 2, std::min(512 / windows, (n + 4 * rows_iter - 1) / (4 * rows_iter))));   // (same rule as tdx_colsum: same sums)
+  const int rows_per_slab = ((n + slabs - 1) / slabs + rows_iter - 1) / rows_iter * rows_iter;
+  slabs = (n + rows_per_slab - 1) / rows_per_slab;
+  hipLaunchKernelGGL(colsum_partial_v4_kernel<4>, dim3((unsigned)slabs, (unsigned)windows, 2u), dim3(256), 0, st, (const float*)xa, ld, n, c, lpr, ws,
+                     rows_per_slab, (const float*)xb);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((c + 15) / 16), 2u), dim3(256), 0, st, ws, slabs, c, outa, accumulate, outb);
+  TDX_CHECK_LAUNCH("colsum_pair");
   return TDX_OK;
 }
 

@@ -244,9 +244,17 @@ class TrainStep:
                 raise TdxError(f"{name}: activation {act} in a conv epilogue has no backward here")
             gptr = go.data_ptr() + 4 * off
             if res is not None:
-                gr = self.G(res)
-                bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout,
-                        0 if self.first_write(res, 0, cout) else 1, F32)
+                # d(res) = dY.  When this is the first write of the residual's gradient and both are plain (B, L, cout) tensors, the residual's
+                # gradient simply IS this buffer from here on: every reader of G(out) is emitted below, before any later launch adds to
+                # G(res), and G(out) has no reader after its producer's backward (a 210 MB copy per identity shortcut otherwise)
+                if (os.environ.get("TDX_TRAIN_ALIAS_DRES", "1") != "0" and ld == cout and off == 0 and tuple(res.shape) == tuple(go.shape)
+                        and id(res) not in self._agrad and id(res) not in self._gwritten):
+                    self.first_write(res, 0, cout)
+                    self._agrad[id(res)] = go
+                else:
+                    gr = self.G(res)
+                    bw.call(name + ".dres", lib.tdx_upsample_fold, go.data_ptr(), ld, off, gr.data_ptr(), gr.shape[-1], 0, B, lout, lout, cout,
+                            0 if self.first_write(res, 0, cout) else 1, F32)
             # the first bias takes its gradient from the first segment's weight-gradient launch (tdx_conv_wgrad_bias); a second bias (the
             # 1x1 shortcut's, same gradient) keeps the stand-alone column sum
             fused_bias = biases[0] if biases and os.environ.get("TDX_TRAIN_FUSE_DBIAS", "1") != "0" else None
@@ -311,8 +319,8 @@ class TrainStep:
                 self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_bwd, *args)
             else:
                 self.bw.call(name + ".bwd", lib.tdx_groupnorm_act_dropout_bwd, *args, drop[0], self.seed, drop[1], self.rng.data_ptr())
-            for rows, p in ((ra, gam), (rb, bet)):
-                self.bw.call(name + ".dparam", lib.tdx_colsum, rows.data_ptr(), Cn, B, Cn, self.PG(p).data_ptr() + 4 * p_off, 1, F32, self.red_ws.data_ptr())
+            self.bw.call(name + ".dparam", lib.tdx_colsum_pair, ra.data_ptr(), rb.data_ptr(), Cn, B, Cn, self.PG(gam).data_ptr() + 4 * p_off,
+                         self.PG(bet).data_ptr() + 4 * p_off, 1, F32, self.red_ws.data_ptr())
         self._back.append(backward)
 
     # ---- the network ------------------------------------------------------------------------------------------------------

@@ -82,6 +82,15 @@ class TrainStep:
         self._gwritten: Dict[int, List[Tuple[int, int]]] = {}
         self._gzero: List[torch.Tensor] = []        # gradient buffers that still need the per-step zero fill
         self._adamw_key, self._adamw_tab = None, None   # device table of the optimizer's tensors (tdx_adamw_step_multi)
+        # Two streams for the backward program: a conv's weight gradient (side stream) and its data gradient (main stream) both read dY and
+        # are independent; at B = 1024 every conv has ~400 tiles for 256 CUs, so a GEMM alone leaves a fifth of the CUs idle in its last
+        # round and the other GEMM's workgroups fill them.  _side_idx: launches that go to the side stream; _join_before: launches in
+        # front of which the main stream waits for it; _side_reads: gradient buffers the outstanding side launches read (while emitting).
+        self._side_idx: set = set()
+        self._join_before: set = set()
+        self._side_reads: set = set()
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        self.two_streams = os.environ.get("TDX_TRAIN_TWO_STREAMS", "1") != "0"
         self._keep: List[torch.Tensor] = []
         self.params = dict(model.named_parameters())
         for n, p in self.params.items():
@@ -118,6 +127,11 @@ class TrainStep:
         g = self._agrad.get(id(t))
         if g is None:
             g = self._agrad[id(t)] = self._new(*t.shape)
+        if id(g) in self._side_reads:
+            # a weight-gradient launch on the side stream may still be reading this buffer: whatever is emitted next (it asked for the
+            # buffer, so it may write it: an aliased shortcut gradient being added to) first joins the side stream
+            self._join_before.add(len(self.bw.ops))
+            self._side_reads.clear()
         return g
 
     def first_write(self, t: torch.Tensor, lo: int = 0, width: Optional[int] = None) -> bool:
@@ -269,6 +283,8 @@ class TrainStep:
                          0, s.ld, s.ch_off, s.cin, s.taps, s.stride, s.lin, s.lvirt, 0)
                 self._keep.append(k)
                 gw = self.PG(s.W)
+                self._side_idx.add(len(bw.ops))
+                self._side_reads.add(id(go))
                 if fused_bias is not None:
                     bw.call(name + ".wgrad", lib.tdx_conv_wgrad_bias, go.data_ptr(), ld, off, cout, C.byref(k), B, lout, gw.data_ptr(), s.W.shape[1],
                             s.w_off, 1, self.PG(fused_bias).data_ptr(), 1, F32, self.ws.data_ptr(), self.ws.numel())
@@ -586,7 +602,10 @@ class TrainStep:
             _lib.check(self.lib.tdx_chanfirst_to_rows(dp.data_ptr(), self.G(self.out4).data_ptr(), self.B, 2, self.L, 4, _lib.TDX_F32, _lib.stream_ptr()),
                        "dpred -> rows")
             if not sync:
-                self.bw.run()
+                if self.two_streams:
+                    self._run_backward_two_streams()
+                else:
+                    self.bw.run()
                 self._fold_padded()
                 return self.named_gradients()
             import torch.distributed as dist
@@ -622,6 +641,31 @@ class TrainStep:
             if world > 1:
                 flat[: self._garena_used].mul_(1.0 / world)
         return self.named_gradients()
+
+    def _run_backward_two_streams(self) -> None:
+        """The backward program with its weight-gradient launches on a side stream (see __init__).  Order on each stream is program
+        order; a side launch waits for everything the main stream was given before it (its dY is complete), the main stream waits for
+        the side stream in front of the launches in _join_before and at the end."""
+        main = torch.cuda.current_stream()
+        if self._side_stream is None or self._side_stream.device != self.dev:
+            self._side_stream = torch.cuda.Stream(device=self.dev)
+        side = self._side_stream
+        st_main, st_side = main.cuda_stream, side.cuda_stream
+        outstanding = False
+        for i, (name, fn, args) in enumerate(self.bw.ops):
+            if outstanding and i in self._join_before:
+                main.wait_stream(side)
+                outstanding = False
+            if i in self._side_idx:
+                side.wait_stream(main)
+                rc = fn(*args, st_side)
+                outstanding = True
+            else:
+                rc = fn(*args, st_main)
+            if rc:
+                _lib.check(rc, name)
+        if outstanding:
+            main.wait_stream(side)
 
     def _fold_padded(self) -> None:
         for q, p, _, where in self._padded:   # fold the gradients of padded / re-viewed stand-ins back into the parameters

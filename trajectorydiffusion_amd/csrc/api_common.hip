@@ -15,7 +15,7 @@ void tdx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tdx_last_error(void) { return g_err; }
-extern "C" int tdx_version(void) { return 210; }
+extern "C" int tdx_version(void) { return 300; }
 
 extern "C" int tdx_device_ok(void) {
   int dev = 0;

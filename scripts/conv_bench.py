@@ -20,6 +20,7 @@ ap.add_argument("--noraw", action="store_true")
 ap.add_argument("--gnact", type=int, default=2)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--only", default="", help="run the shapes whose name contains this")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 B = a.batch
@@ -33,6 +34,8 @@ lib = _lib.lib()
 forces = a.force if a.force is not None else [1 if a.small else 0]
 print(f"{'shape':22s} " + " ".join(f"f{f}/dbg{d}: ms / TF  " for f in forces for d in a.debug))
 for name, L, ci, co, k in SHAPES:
+    if a.only not in name:
+        continue
     x = torch.randn((B, L, ci), device="cuda").to(dt)
     w = (torch.randn((co, k * ci), device="cuda") / (k * ci) ** 0.5).to(dt)
     bias = torch.randn(co, device="cuda")
@@ -51,7 +54,7 @@ for name, L, ci, co, k in SHAPES:
     combos = [(f, d) for f in forces for d in a.debug]
     best = [1e9] * len(combos)
     for rnd in range(4):  # interleaved rounds, best of 4: clocks drift by a few % within a process
-        for ci, (f, d) in enumerate(combos):
+        for cidx, (f, d) in enumerate(combos):
             lib.tdx_conv_gemm_force_small(f)
             lib.tdx_conv_gemm_debug(d)
             for _ in range(2):
@@ -63,7 +66,7 @@ for name, L, ci, co, k in SHAPES:
                 pg.run()
             e1.record()
             torch.cuda.synchronize()
-            best[ci] = min(best[ci], e0.elapsed_time(e1) / 10)
+            best[cidx] = min(best[cidx], e0.elapsed_time(e1) / 10)
     cells = [f"{ms:7.3f} / {fl / ms / 1e9:6.0f}" for ms in best]
     lib.tdx_conv_gemm_debug(0)
     lib.tdx_conv_gemm_force_small(0)

@@ -621,17 +621,22 @@ class TrainStep:
                 nonlocal k
                 if k < len(plan) and plan[k][2] <= done:
                     comm.wait_stream(main)        # orders the collective after the launches issued so far, not after later ones
+                    if self.two_streams and self._side_stream is not None:
+                        comm.wait_stream(self._side_stream)   # (the weight gradients are written on the side stream)
                     while k < len(plan) and plan[k][2] <= done:
                         lo, hi, _ = plan[k]
                         with torch.cuda.stream(comm):
                             pending.append((allreduce_slice_async(flat[lo:hi], sync_group), lo, hi))
                         k += 1
-            st = _lib.stream_ptr()
-            for i, (name, fn, args) in enumerate(self.bw.ops):
-                rc = fn(*args, st)
-                if rc:
-                    _lib.check(rc, name)
-                start_ready(i)
+            if self.two_streams:
+                self._run_backward_two_streams(after=start_ready)
+            else:
+                st = _lib.stream_ptr()
+                for i, (name, fn, args) in enumerate(self.bw.ops):
+                    rc = fn(*args, st)
+                    if rc:
+                        _lib.check(rc, name)
+                    start_ready(i)
             self._fold_padded()
             start_ready(len(self.bw.ops))
             for work, lo, hi in pending:
@@ -642,10 +647,11 @@ class TrainStep:
                 flat[: self._garena_used].mul_(1.0 / world)
         return self.named_gradients()
 
-    def _run_backward_two_streams(self) -> None:
+    def _run_backward_two_streams(self, after: Optional[Callable[[int], None]] = None) -> None:
         """The backward program with its weight-gradient launches on a side stream (see __init__).  Order on each stream is program
         order; a side launch waits for everything the main stream was given before it (its dY is complete), the main stream waits for
-        the side stream in front of the launches in _join_before and at the end."""
+        the side stream in front of the launches in _join_before and at the end.  after(i) is called once launch i has been issued
+        (the data-parallel path starts the all-reduce of the gradient slices that launch completes)."""
         main = torch.cuda.current_stream()
         if self._side_stream is None or self._side_stream.device != self.dev:
             self._side_stream = torch.cuda.Stream(device=self.dev)
@@ -664,6 +670,8 @@ class TrainStep:
                 rc = fn(*args, st_main)
             if rc:
                 _lib.check(rc, name)
+            if after is not None:
+                after(i)
         if outstanding:
             main.wait_stream(side)
 
